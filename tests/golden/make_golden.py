@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""Generate golden vectors for the render path by IMPORTING the reference.
+
+Runs only in the build container (needs /root/reference, which never travels to
+the GPU box).  Output: small .npz files next to this script; they hold DATA only
+(inputs, the reference's intermediates and outputs) -- no reference source.
+
+Captured per fixture:
+  inputs   : feature_volume (B,C,V,V,V channel-first, as the encoder emits),
+             global_feature, cam2worlds, every parameter of generator.siren
+             (state-dict names), the RNG tensors in draw order
+             (u_strat, eps_coarse, u_fine, eps_final)
+  interm.  : world points / jittered z of the coarse pass, looked-up features,
+             coarse rgb_sigma, coarse weights, cdf, inds, fine z, fine rgb_sigma,
+             sort indices, final weights
+  outputs  : pixels, depth_map
+  backward : grads of  pixels.square().mean() + depth.mean()  w.r.t. every
+             parameter, feature_volume, global_feature
+
+Usage:  python tests/golden/make_golden.py [name ...]
+"""
+import os
+import sys
+import math
+
+os.environ.setdefault("MPLBACKEND", "Agg")
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+FOV = 49.134342641202636
+RAY_START, RAY_END = 0.25, 1.95
+
+# name -> spec.  "full": store all intermediates + grads; otherwise a slim set.
+FIXTURES = {
+    # cfg-1 shape (32x32x12, B=2), primary variant, full hidden width
+    "short_fg_32x12": dict(variant="SHORTSIREN_FG", B=2, R=32, S=12, V=16, C=32, H=256, Z=256,
+                           noise=0.0, clamp="relu", white_back=True, last_back=False, seed=0, full=False,
+                           grads=False),
+    # cfg-2 numerics gate (64x64x24, B=1)
+    "short_fg_64x24": dict(variant="SHORTSIREN_FG", B=1, R=64, S=24, V=24, C=32, H=256, Z=256,
+                           noise=0.0, clamp="relu", white_back=True, last_back=False, seed=1, full=False,
+                           grads=False),
+    # small-width variants with every toggle, intermediates and grads
+    "short_fg_small": dict(variant="SHORTSIREN_FG", B=2, R=16, S=12, V=12, C=32, H=64, Z=48,
+                           noise=0.5, clamp="relu", white_back=True, last_back=False, seed=2, full=True,
+                           grads=True),
+    "tall_fg_small": dict(variant="TALLSIREN_FG", B=1, R=16, S=8, V=10, C=32, H=64, Z=48,
+                          noise=0.0, clamp="softplus", white_back=False, last_back=True, seed=3, full=True,
+                          grads=True),
+    "double_fg_small": dict(variant="DOUBLESIREN_FG", B=2, R=12, S=16, V=8, C=32, H=64, Z=32,
+                            noise=0.5, clamp="softplus", white_back=True, last_back=True, seed=4, full=True,
+                            grads=True),
+    "single_dg_small": dict(variant="SingleSIREN_dg", B=1, R=16, S=12, V=12, C=32, H=64, Z=48,
+                            noise=0.0, clamp="relu", white_back=False, last_back=False, seed=5, full=True,
+                            grads=True),
+    "short_f_small": dict(variant="SHORTSIREN_F", B=1, R=16, S=12, V=12, C=32, H=64, Z=32,
+                          noise=0.0, clamp="relu", white_back=True, last_back=False, seed=6, full=True,
+                          grads=True),
+    "short_fres_small": dict(variant="SHORTSIREN_FRes", B=1, R=16, S=12, V=12, C=32, H=64, Z=32,
+                             noise=0.0, clamp="relu", white_back=True, last_back=False, seed=7, full=True,
+                             grads=True),
+    "tall_dres_small": dict(variant="TALLSIREN_dRes", B=1, R=16, S=12, V=12, C=32, H=64, Z=32,
+                            noise=0.0, clamp="relu", white_back=True, last_back=False, seed=8, full=True,
+                            grads=True),
+    # non-hierarchical single pass
+    "short_fg_nohier": dict(variant="SHORTSIREN_FG", B=1, R=16, S=12, V=12, C=32, H=64, Z=48,
+                            noise=0.0, clamp="relu", white_back=True, last_back=False, seed=9, full=True,
+                            grads=True, hierarchical=False),
+    # S > 32 (several MFMA point tiles per ray, multi-chunk scans)
+    "short_fg_s40": dict(variant="SHORTSIREN_FG", B=1, R=8, S=40, V=12, C=32, H=64, Z=48,
+                         noise=0.0, clamp="relu", white_back=True, last_back=False, seed=10, full=True,
+                         grads=True),
+}
+
+# variants whose `z` is the bare feature volume (no global feature)
+NO_GLOBAL = {"SHORTSIREN_F", "SHORTSIREN_FRes", "TALLSIREN_dRes", "TALLSIREN_dResLong", "TALLSIREN"}
+
+
+def build(name):
+    spec = FIXTURES[name]
+    sys.path.insert(0, REF)
+    from generators import generators as ref_gen          # noqa: E402
+    from generators import volumetric_rendering as ref_vr  # noqa: E402
+
+    torch.manual_seed(spec["seed"])
+    np.random.seed(spec["seed"])
+    B, R, S, V, C, H, Z = (spec[k] for k in "BRSVCHZ")
+    hier = spec.get("hierarchical", True)
+
+    variant = spec["variant"]
+    # FG family: FiLMLayer(input_dim, hidden) eats the looked-up feature -> input_dim = C,
+    # z_dim = width of the global feature.  Plain-sine families set input_dim = z_dim themselves.
+    if variant in NO_GLOBAL:
+        gen = ref_gen.ImplicitGenerator3d(variant, z_dim=C, input_dim=C, output_dim=4, hidden_dim=H)
+    else:
+        gen = ref_gen.ImplicitGenerator3d(variant, z_dim=Z, input_dim=C, output_dim=4, hidden_dim=H)
+    gen.set_device(torch.device("cpu"))
+    gen.eval()
+    # Default init gives near-zero densities (an all-background image pins nothing): scale the head so
+    # that sigma spans both signs at O(1..10) and colours leave the sigmoid's linear range.  The scaled
+    # values are stored in the fixture like every other parameter.
+    with torch.no_grad():
+        gen.siren.final_layer.weight[:3] *= 6.0
+        gen.siren.final_layer.weight[3] *= 40.0
+        gen.siren.final_layer.bias[3] += 0.25
+
+    fvol = (torch.randn(B, C, V, V, V) * 0.5).requires_grad_(True)
+    glob = torch.randn(B, Z).requires_grad_(True)
+    origins = ref_vr.sample_camera_positions(torch.device("cpu"), "y", cam_r_start=0.7, cam_r_end=1.5, n=B)
+    cam2world = ref_vr.create_cam2world_matrix(origins, "y", device=torch.device("cpu")).float()
+
+    rec = {"rand": [], "randn": [], "feat": [], "siren_in": [], "siren_out": [], "weights": [],
+           "z_in": [], "cdf": [], "inds": [], "fine_z": [], "sort_idx": []}
+
+    o_rand, o_randn, o_gs, o_ss, o_sort = torch.rand, torch.randn, F.grid_sample, torch.searchsorted, torch.sort
+    o_fi, o_sp = ref_gen.fancy_integration, ref_gen.sample_pdf
+
+    def w_rand(*a, **k):
+        t = o_rand(*a, **k); rec["rand"].append(t.detach().clone()); return t
+
+    def w_randn(*a, **k):
+        t = o_randn(*a, **k); rec["randn"].append(t.detach().clone()); return t
+
+    def w_gs(*a, **k):
+        t = o_gs(*a, **k); rec["feat"].append(t.detach().clone()); return t
+
+    def w_ss(cdf, u, **k):
+        t = o_ss(cdf, u, **k); rec["cdf"].append(cdf.detach().clone()); rec["inds"].append(t.clone()); return t
+
+    def w_sort(*a, **k):
+        t = o_sort(*a, **k); rec["sort_idx"].append(t[1].clone()); return t
+
+    def w_fi(rgb_sigma, z_vals, **k):
+        out = o_fi(rgb_sigma, z_vals, **k)
+        rec["weights"].append(out[2].detach().clone()); rec["z_in"].append(z_vals.detach().clone())
+        return out
+
+    def w_sp(*a, **k):
+        t = o_sp(*a, **k); rec["fine_z"].append(t.detach().clone()); return t
+
+    def siren_hook(_m, inp, outp):
+        rec["siren_in"].append(inp[0].detach().clone())
+        rec["siren_out"].append(outp.detach().clone())
+
+    hook = gen.siren.register_forward_hook(siren_hook)
+    torch.rand, torch.randn, F.grid_sample, torch.searchsorted, torch.sort = w_rand, w_randn, w_gs, w_ss, w_sort
+    ref_gen.fancy_integration, ref_gen.sample_pdf = w_fi, w_sp
+    try:
+        z = fvol if variant in NO_GLOBAL else (fvol, glob)
+        kw = dict(clamp_mode=spec["clamp"], nerf_noise=spec["noise"], white_back=spec["white_back"],
+                  last_back=spec["last_back"],
+                  # the caller splats its whole metadata dict: extra keys must be ignored
+                  batch_size=B, generator={"siren_type": variant})
+        pixels, depth = gen(z, cam2world, R, FOV, RAY_START, RAY_END, S, hier, **kw)
+    finally:
+        torch.rand, torch.randn, F.grid_sample, torch.searchsorted, torch.sort = o_rand, o_randn, o_gs, o_ss, o_sort
+        ref_gen.fancy_integration, ref_gen.sample_pdf = o_fi, o_sp
+        hook.remove()
+
+    out = {}
+    meta = dict(spec)
+    meta.update(fov=FOV, ray_start=RAY_START, ray_end=RAY_END, torch=torch.__version__, name=name,
+                hierarchical=hier, has_global=variant not in NO_GLOBAL)
+    out["meta_json"] = np.frombuffer(__import__("json").dumps(meta).encode(), dtype=np.uint8)
+    out["feature_volume"] = fvol.detach().numpy()
+    if variant not in NO_GLOBAL:
+        out["global_feature"] = glob.detach().numpy()
+    out["cam2worlds"] = cam2world.numpy()
+    for k, v in gen.state_dict().items():
+        out["param/" + k] = v.numpy()
+
+    # RNG tensors in draw order: rand(B,R2,S,1) randn(B,R2,S,1) rand(BR2,S) randn(B,R2,2S,1)
+    out["u_strat"] = rec["rand"][0].numpy().reshape(B, R * R, S)
+    if hier:
+        assert len(rec["rand"]) == 2 and len(rec["randn"]) == 2
+        out["u_fine"] = rec["rand"][1].numpy().reshape(B, R * R, S)
+        if spec["noise"] != 0:
+            out["eps_coarse"] = rec["randn"][0].numpy().reshape(B, R * R, S)
+            out["eps_final"] = rec["randn"][1].numpy().reshape(B, R * R, 2 * S)
+    else:
+        assert len(rec["rand"]) == 1 and len(rec["randn"]) == 1
+        if spec["noise"] != 0:
+            out["eps_final"] = rec["randn"][0].numpy().reshape(B, R * R, S)
+
+    out["pixels"] = pixels.detach().numpy()
+    out["depth"] = depth.detach().numpy()
+    out["coarse_rgb_sigma"] = rec["siren_out"][0].numpy().reshape(B, R * R, S, 4)
+    out["coarse_z"] = rec["z_in"][0].numpy().reshape(B, R * R, S)
+    if hier:
+        out["fine_rgb_sigma"] = rec["siren_out"][1].numpy().reshape(B, R * R, S, 4)
+        out["fine_z"] = rec["fine_z"][0].numpy().reshape(B, R * R, S)
+        out["inds"] = rec["inds"][0].numpy().reshape(B, R * R, S).astype(np.int16)
+        out["sort_idx"] = rec["sort_idx"][0].numpy().reshape(B, R * R, 2 * S).astype(np.int16)
+        out["coarse_weights"] = rec["weights"][0].numpy().reshape(B, R * R, S)
+    if spec["full"]:
+        out["coarse_points"] = rec["siren_in"][0].numpy().reshape(B, R * R, S, 3)
+        out["coarse_feat"] = rec["feat"][0].numpy().reshape(B, C, R * R * S).transpose(0, 2, 1).copy()
+        out["final_weights"] = rec["weights"][-1].numpy().reshape(B, R * R, -1)
+        if hier:
+            out["cdf"] = rec["cdf"][0].numpy().reshape(B, R * R, S - 1)
+            out["fine_points"] = rec["siren_in"][1].numpy().reshape(B, R * R, S, 3)
+
+    if spec["grads"]:
+        loss = pixels.square().mean() + depth.mean()
+        params = dict(gen.named_parameters())
+        leaves = list(params.values()) + [fvol] + ([] if variant in NO_GLOBAL else [glob])
+        grads = torch.autograd.grad(loss, leaves, allow_unused=True)
+        for (k, _), g in zip(params.items(), grads):
+            out["grad/" + k] = (g if g is not None else torch.zeros_like(params[k])).numpy()
+        out["grad_feature_volume"] = grads[len(params)].numpy()
+        if variant not in NO_GLOBAL:
+            out["grad_global_feature"] = grads[len(params) + 1].numpy()
+        out["loss"] = np.float32(loss.item())
+
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: {os.path.getsize(path)/1e6:.2f} MB  pixels[{pixels.min():.3f},{pixels.max():.3f}] "
+          f"depth[{depth.min():.3f},{depth.max():.3f}]")
+
+
+if __name__ == "__main__":
+    names = sys.argv[1:] or list(FIXTURES)
+    for n in names:
+        build(n)
