@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""Headline benchmark of the render path: rays/s of ImplicitGenerator3d.forward at 128x128x64 spp on synthetic
+ShapeNetCar-shaped inputs (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A step = one generator forward over this rank's B images (the four random draws, FiLM mapping, channel-last copy of the
+feature volume, weight packing, coarse pass, resampling, fine pass, merge + composite).  Inputs are resident in HBM
+before the timed region.  Rank 0 prints ONE JSON line with the whole-job rays/s, the roofline of the dominant kernel
+(timed with HIP events recorded inside the timed region) and, at N=1, the CPU oracle timed on a bounded sample.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+FOV, RAY_START, RAY_END = 49.134342641202636, 0.25, 1.95     # configs/thousand/special.py:35-41 of the reference
+PEAK_F32_MFMA_TFLOPS = 157.3                                  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBPS = 8000.0
+
+
+def macs_per_point(C, H, n_layers):
+    return C * H + (n_layers - 1) * H * H + H * 4             # SHORTSIREN_FG: 205,824
+
+
+class HipEvents:
+    """hipEvent_t pairs through ctypes (the C ABI records them around the field kernel on the launch stream)."""
+
+    def __init__(self):
+        self.hip = ctypes.CDLL("libamdhip64.so")
+        self.hip.hipEventCreate.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
+        self.hip.hipEventElapsedTime.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, ctypes.c_void_p]
+        self.hip.hipEventSynchronize.argtypes = [ctypes.c_void_p]
+        self.hip.hipEventDestroy.argtypes = [ctypes.c_void_p]
+
+    def create(self, n):
+        out = []
+        for _ in range(n):
+            e = ctypes.c_void_p()
+            assert self.hip.hipEventCreate(ctypes.byref(e)) == 0
+            out.append(e.value)
+        return out
+
+    def elapsed_ms(self, a, b):
+        ms = ctypes.c_float()
+        assert self.hip.hipEventSynchronize(b) == 0
+        assert self.hip.hipEventElapsedTime(ctypes.byref(ms), a, b) == 0
+        return ms.value
+
+
+def synthetic_inputs(B, V, Z, dev, seed):
+    """ShapeNetCar-shaped synthetic inputs: unet3d-like feature volume, global feature, cameras."""
+    from cnerf_amd.generators.volumetric_rendering import sample_camera_positions, create_cam2world_matrix
+    g = torch.Generator().manual_seed(seed)
+    fvol = torch.randn(B, 32, V, V, V, generator=g)
+    glob = torch.randn(B, Z, generator=g)
+    np.random.seed(seed)
+    cam = create_cam2world_matrix(sample_camera_positions("cpu", "y", 0.7, 1.5, B), "y")
+    return fvol.to(dev), glob.to(dev), cam.to(dev)
+
+
+def cpu_baseline(args, gen_cpu):
+    """The CPU oracle (same ATen op sequence as the reference's CPU path) on one image of the same workload."""
+    from oracle import render_oracle as O
+    R, S = args.img_size, args.num_steps
+    g = torch.Generator().manual_seed(1234)
+    fvol = torch.randn(1, 32, args.volume, args.volume, args.volume, generator=g)
+    glob = torch.randn(1, args.z_dim, generator=g)
+    cam = torch.eye(4).unsqueeze(0).clone()
+    cam[0, 2, 3] = -1.0
+    params = {k: v.detach() for k, v in gen_cpu.siren.state_dict().items()}
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    times = []
+    with torch.no_grad():
+        for i in range(1 + args.cpu_reps):
+            u1, u2 = torch.rand(1, R * R, S, generator=g), torch.rand(1, R * R, S, generator=g)
+            t0 = time.perf_counter()
+            O.render(args.variant, params, fvol, glob, cam, R, FOV, RAY_START, RAY_END, S, True, "relu", 0.0, True, False,
+                     u1, None, u2, None)
+            dt = time.perf_counter() - t0
+            if i > 0:
+                times.append(dt)
+    t = float(np.median(times))
+    return {"value": R * R / t, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"1 image {R}x{R}x{S} hierarchical fp32 no_grad, median of {args.cpu_reps} after 1 warm-up "
+                      f"({t:.2f} s each), oracle/render_oracle.py (ATen op sequence of the reference CPU path)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--img-size", type=int, default=128)
+    ap.add_argument("--num-steps", type=int, default=64)
+    ap.add_argument("--batch", type=int, default=8, help="images per GPU per step (BASELINE config 4: 8/GPU)")
+    ap.add_argument("--volume", type=int, default=64)
+    ap.add_argument("--variant", default="SHORTSIREN_FG")
+    ap.add_argument("--hidden", type=int, default=256)
+    ap.add_argument("--z-dim", type=int, default=256)
+    ap.add_argument("--noise", type=float, default=0.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-reps", type=int, default=2)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)     # RCCL; only the barrier and the max-over-ranks use it
+
+    import __graft_entry__ as ge
+    if rank == 0:
+        ge.build()
+    if world > 1:
+        dist.barrier()
+    import cnerf_amd
+    from cnerf_amd.generators import ImplicitGenerator3d
+
+    torch.manual_seed(0)                                      # reference default init under seed 0
+    gen_cpu = ImplicitGenerator3d(args.variant, args.z_dim, 32, 4, args.hidden)
+    import copy
+    gen = copy.deepcopy(gen_cpu).to(dev)
+    gen.set_device(dev)
+    gen.eval()
+    B, R, S = args.batch, args.img_size, args.num_steps
+    fvol, glob, cam = synthetic_inputs(B, args.volume, args.z_dim, dev, seed=rank)
+    meta = dict(clamp_mode="relu", nerf_noise=args.noise, white_back=True, hierarchical_sample=True)
+
+    evs = HipEvents()
+    n_ev = 4 * args.steps
+    events = evs.create(n_ev)
+
+    def step(i=None):
+        ev = events[4 * i:4 * i + 4] if i is not None else None
+        cnerf_amd.ops._pack_cache.clear()                     # training changes the weights every step: re-pack
+        with torch.no_grad():
+            return gen((fvol, glob), cam, R, FOV, RAY_START, RAY_END, S, _field_events=ev, **meta)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    assert torch.isfinite(out[0]).all()
+
+    # dominant kernel: field_tile_kernel, two launches per step (coarse, fine), same work each
+    kern_ms = []
+    for i in range(args.steps):
+        e = events[4 * i:4 * i + 4]
+        kern_ms += [evs.elapsed_ms(e[0], e[1]), evs.elapsed_ms(e[2], e[3])]
+    avg_ms = float(np.mean(kern_ms))
+    n_layers = len(gen.siren.spec.layers)
+    flops_per_launch = 2.0 * macs_per_point(32, args.hidden, n_layers) * B * R * R * S
+    achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
+
+    if rank == 0:
+        rays = world * B * R * R * args.steps
+        res = {
+            "metric": "rays/sec at 128x128x64spp ShapeNetCar",
+            "value": rays / elapsed, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"ImplicitGenerator3d.forward {args.variant} hidden {args.hidden}, {R}x{R} rays x {S} "
+                                   f"coarse + {S} fine samples, feature volume 32x{args.volume}^3, batch {B}/GPU, "
+                                   f"hierarchical, white_back, relu, nerf_noise {args.noise}",
+                       "img_size": R, "num_steps": S, "images_per_gpu": B, "mpts_per_s": rays / elapsed * 2 * S / 1e6,
+                       "parallelism": f"image-batch data parallel x{world}, no data-path collective"},
+            "roofline": {"kernel": "field_tile_kernel<8> (sample + trilinear lookup + FiLM-SIREN MLP, fp32 MFMA)",
+                         "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "avg_launch_ms": avg_ms, "launches": len(kern_ms),
+                         "flops_per_launch": flops_per_launch,
+                         "share_of_step": 2 * avg_ms / (elapsed / args.steps * 1e3)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(args, gen_cpu)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

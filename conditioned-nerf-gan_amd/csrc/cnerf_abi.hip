@@ -1,0 +1,297 @@
+// C-ABI entry points of libcnerf_hip.so (declared in include/cnerf.h).  Host-side only: argument validation, buffer
+// carving, launch sequencing on the caller's stream.  No allocation, no synchronisation, no global state.
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "cnerf_kernels.hpp"
+
+using namespace cnerf;
+
+namespace {
+
+thread_local char g_err[256] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int hip_fail(hipError_t e, const char* what) {
+    return fail(CNERF_ELAUNCH, "%s: %s", what, hipGetErrorString(e));
+}
+
+size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+int check_cfg(const cnerf_cfg* c, bool need_render) {
+    if (!c) return fail(CNERF_EINVAL, "cfg is NULL");
+    if (c->B < 1) return fail(CNERF_EINVAL, "B=%d must be >= 1", c->B);
+    if (c->C != 32) return fail(CNERF_EINVAL, "C=%d: this build supports 32 feature channels", c->C);
+    if (c->H != 64 && c->H != 128 && c->H != 256) return fail(CNERF_EINVAL, "H=%d must be 64, 128 or 256", c->H);
+    if (c->V < 2 || c->V > 1024) return fail(CNERF_EINVAL, "V=%d out of range [2,1024]", c->V);
+    if (c->L < 1 || c->L > CNERF_MAX_LAYERS) return fail(CNERF_EINVAL, "L=%d out of range [1,%d]", c->L, CNERF_MAX_LAYERS);
+    for (int l = 0; l < c->L; ++l) {
+        const int k = c->layer_kind[l];
+        if (k != CNERF_LAYER_FILM && k != CNERF_LAYER_SINE && k != CNERF_LAYER_RES)
+            return fail(CNERF_EINVAL, "layer_kind[%d]=%d unknown", l, k);
+        if (l == 0 && k == CNERF_LAYER_RES) return fail(CNERF_EINVAL, "layer 0 cannot be a residual block");
+    }
+    if (!(c->voxel_length > 0.f)) return fail(CNERF_EINVAL, "voxel_length must be > 0");
+    if (need_render) {
+        if (c->R < 1 || c->R > 4096) return fail(CNERF_EINVAL, "R=%d out of range [1,4096]", c->R);
+        if (c->S < 2 || c->S > 128) return fail(CNERF_EINVAL, "S=%d out of range [2,128]", c->S);
+        if (!(c->fov_deg > 0.0 && c->fov_deg < 180.0)) return fail(CNERF_EINVAL, "fov_deg out of (0,180)");
+    }
+    return CNERF_OK;
+}
+
+// packed layout: [float4 weight stream][biases of every layer in order (RES: b1 then b2)][head bias (4)]
+struct PackedLayout {
+    size_t weight_floats;
+    size_t bias_floats;
+    int n_film;
+};
+
+PackedLayout packed_layout(const cnerf_cfg* c) {
+    const size_t NT = c->H / 32;
+    const size_t tile = 4 * 64 * 4;  // floats per (t, tk) pair
+    PackedLayout p{0, 0, 0};
+    for (int l = 0; l < c->L; ++l) {
+        const size_t kt = (l == 0) ? 1 : NT;
+        if (c->layer_kind[l] == CNERF_LAYER_RES) {
+            p.weight_floats += 2 * NT * NT * tile;
+            p.bias_floats += 2 * c->H;
+        } else {
+            p.weight_floats += NT * kt * tile;
+            p.bias_floats += c->H;
+            if (c->layer_kind[l] == CNERF_LAYER_FILM) p.n_film++;
+        }
+    }
+    p.weight_floats += 1 * NT * tile;  // head, one 32-row tile
+    p.bias_floats += 4;
+    return p;
+}
+
+RayGeom make_geom(const cnerf_cfg* c) {
+    RayGeom g;
+    g.R = c->R;
+    g.S = c->S;
+    // z = ones(float32) / np.tan((2*pi*fov/360)/2): the double tangent is rounded to fp32, then 1/x in fp32
+    g.focal = 1.0f / (float)tan((2.0 * M_PI * c->fov_deg / 360.0) / 2.0);
+    g.ray_start = c->ray_start;
+    g.ray_end = c->ray_end;
+    return g;
+}
+
+void fill_field_args(FieldArgs& a, const cnerf_cfg* c, const float* fvol_cl, const float* packed, const float* freq,
+                     const float* phase) {
+    memset(&a, 0, sizeof(a));
+    const PackedLayout pl = packed_layout(c);
+    a.fvol = fvol_cl;
+    a.packed = packed;
+    a.bias = packed + pl.weight_floats;
+    a.freq = pl.n_film ? freq : nullptr;
+    a.phase = pl.n_film ? phase : nullptr;
+    a.film_stride = pl.n_film * c->H;
+    a.geom = make_geom(c);
+    a.half_voxel = c->voxel_length / 2.0f;
+    a.V = c->V;
+    a.L = c->L;
+    a.flags = c->flags;
+    for (int l = 0; l < c->L; ++l) a.layer_kind[l] = c->layer_kind[l];
+}
+
+void set_points(FieldArgs& a, int B, long long n_per_image) {
+    a.n_per_image = n_per_image;
+    a.tiles_per_image = (n_per_image + 31) / 32;
+    a.total_tiles = a.tiles_per_image * B;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cnerf_abi_version(void) { return CNERF_ABI_VERSION; }
+
+const char* cnerf_last_error(void) { return g_err; }
+
+int cnerf_workspace_bytes(const cnerf_cfg* cfg, size_t* packed, size_t* fvol_cl, size_t* fwd_ws) {
+    g_err[0] = 0;
+    if (int rc = check_cfg(cfg, fwd_ws != nullptr)) return rc;
+    const PackedLayout pl = packed_layout(cfg);
+    if (packed) *packed = align256((pl.weight_floats + pl.bias_floats) * sizeof(float));
+    if (fvol_cl) *fvol_cl = align256((size_t)cfg->B * cfg->V * cfg->V * cfg->V * cfg->C * sizeof(float));
+    if (fwd_ws) {
+        const size_t N = (size_t)cfg->B * cfg->R * cfg->R * cfg->S;
+        // coarse rgb_sigma + z, fine z + rgb_sigma
+        *fwd_ws = 2 * align256(N * 4 * sizeof(float)) + 2 * align256(N * sizeof(float));
+    }
+    return CNERF_OK;
+}
+
+int cnerf_fvol_channel_last(int32_t B, int32_t C, int32_t V, const float* fvol_cf, float* fvol_cl, void* stream) {
+    g_err[0] = 0;
+    if (B < 1 || V < 1 || C != 32 || !fvol_cf || !fvol_cl) return fail(CNERF_EINVAL, "fvol_channel_last: bad argument (C must be 32)");
+    if (hipError_t e = launch_transpose_cl(B, C, V, fvol_cf, fvol_cl, true, (hipStream_t)stream)) return hip_fail(e, "transpose");
+    return CNERF_OK;
+}
+
+int cnerf_fvol_channel_first(int32_t B, int32_t C, int32_t V, const float* fvol_cl, float* fvol_cf, void* stream) {
+    g_err[0] = 0;
+    if (B < 1 || V < 1 || C != 32 || !fvol_cf || !fvol_cl) return fail(CNERF_EINVAL, "fvol_channel_first: bad argument (C must be 32)");
+    if (hipError_t e = launch_transpose_cl(B, C, V, fvol_cl, fvol_cf, false, (hipStream_t)stream)) return hip_fail(e, "transpose");
+    return CNERF_OK;
+}
+
+int cnerf_pack_field(const cnerf_cfg* cfg, const cnerf_field_params* p, float* packed, void* stream_) {
+    g_err[0] = 0;
+    if (int rc = check_cfg(cfg, false)) return rc;
+    if (!p || !packed) return fail(CNERF_EINVAL, "pack_field: NULL argument");
+    hipStream_t stream = (hipStream_t)stream_;
+    const PackedLayout pl = packed_layout(cfg);
+    const int H = cfg->H, NT = H / 32;
+    float* wdst = packed;
+    float* bdst = packed + pl.weight_floats;
+    const size_t tile = 4 * 64 * 4;
+    for (int l = 0; l < cfg->L; ++l) {
+        const int K = (l == 0) ? cfg->C : H;
+        if (!p->w[l] || !p->b[l]) return fail(CNERF_EINVAL, "pack_field: layer %d weight/bias is NULL", l);
+        if (hipError_t e = launch_pack_matrix(p->w[l], H, K, NT, wdst, stream)) return hip_fail(e, "pack_matrix");
+        wdst += (size_t)NT * (K / 32) * tile;
+        if (hipError_t e = hipMemcpyAsync(bdst, p->b[l], H * sizeof(float), hipMemcpyDeviceToDevice, stream)) return hip_fail(e, "bias copy");
+        bdst += H;
+        if (cfg->layer_kind[l] == CNERF_LAYER_RES) {
+            if (!p->w2[l] || !p->b2[l]) return fail(CNERF_EINVAL, "pack_field: residual layer %d fc2 is NULL", l);
+            if (hipError_t e = launch_pack_matrix(p->w2[l], H, H, NT, wdst, stream)) return hip_fail(e, "pack_matrix");
+            wdst += (size_t)NT * NT * tile;
+            if (hipError_t e = hipMemcpyAsync(bdst, p->b2[l], H * sizeof(float), hipMemcpyDeviceToDevice, stream)) return hip_fail(e, "bias copy");
+            bdst += H;
+        }
+    }
+    if (!p->w_final || !p->b_final) return fail(CNERF_EINVAL, "pack_field: head is NULL");
+    if (hipError_t e = launch_pack_matrix(p->w_final, 4, H, 1, wdst, stream)) return hip_fail(e, "pack_matrix");
+    if (hipError_t e = hipMemcpyAsync(bdst, p->b_final, 4 * sizeof(float), hipMemcpyDeviceToDevice, stream)) return hip_fail(e, "bias copy");
+    return CNERF_OK;
+}
+
+int cnerf_gather_features(const cnerf_cfg* cfg, const float* fvol_cl, const float* points, int64_t n_per_image,
+                          float* feat, void* stream) {
+    g_err[0] = 0;
+    if (int rc = check_cfg(cfg, false)) return rc;
+    if (!fvol_cl || !points || !feat || n_per_image < 1) return fail(CNERF_EINVAL, "gather_features: bad argument");
+    GatherArgs a{fvol_cl, points, feat, (long long)n_per_image, cfg->B, cfg->V, cfg->C, cfg->voxel_length / 2.0f};
+    if (hipError_t e = launch_gather(a, (hipStream_t)stream)) return hip_fail(e, "gather");
+    return CNERF_OK;
+}
+
+int cnerf_field_forward(const cnerf_cfg* cfg, const float* fvol_cl, const float* packed, const float* freq,
+                        const float* phase, const float* points, int64_t n_per_image, float* rgb_sigma, void* stream) {
+    g_err[0] = 0;
+    if (int rc = check_cfg(cfg, false)) return rc;
+    if (!fvol_cl || !packed || !points || !rgb_sigma || n_per_image < 1) return fail(CNERF_EINVAL, "field_forward: bad argument");
+    const PackedLayout pl = packed_layout(cfg);
+    if (pl.n_film && (!freq || !phase)) return fail(CNERF_EINVAL, "field_forward: FiLM layers need freq and phase");
+    FieldArgs a;
+    fill_field_args(a, cfg, fvol_cl, packed, freq, phase);
+    a.mode = FIELD_MODE_POINTS;
+    a.points = points;
+    a.rgb_sigma = rgb_sigma;
+    set_points(a, cfg->B, n_per_image);
+    if (hipError_t e = launch_field(a, cfg->H, (hipStream_t)stream)) return hip_fail(e, "field kernel");
+    return CNERF_OK;
+}
+
+int cnerf_composite(const cnerf_cfg* cfg, int64_t rays, int32_t n, const float* rgb_sigma, const float* z,
+                    const float* eps, float* rgb, float* dist, float* weights, void* stream) {
+    g_err[0] = 0;
+    if (!cfg || rays < 1 || n < 1 || n > 256 || !rgb_sigma || !z) return fail(CNERF_EINVAL, "composite: bad argument (1 <= n <= 256)");
+    CompositeArgs a{rgb_sigma, z, eps, rgb, dist, weights, (long long)rays, n, cfg->noise_std, cfg->flags};
+    if (hipError_t e = launch_composite(a, (hipStream_t)stream)) return hip_fail(e, "composite");
+    return CNERF_OK;
+}
+
+int cnerf_resample(int64_t rays, int32_t S, const float* z, const float* weights, const float* u, float* fine_z,
+                   int32_t* inds, float* cdf, void* stream) {
+    g_err[0] = 0;
+    if (rays < 1 || S < 2 || S > 128 || !z || !weights || !u || !fine_z) return fail(CNERF_EINVAL, "resample: bad argument (2 <= S <= 128)");
+    ResampleArgs a{z, weights, nullptr, nullptr, u, fine_z, inds, cdf, nullptr, (long long)rays, S, 0.0f, 0u};
+    if (hipError_t e = launch_resample(a, (hipStream_t)stream)) return hip_fail(e, "resample");
+    return CNERF_OK;
+}
+
+int cnerf_render_forward(const cnerf_cfg* cfg, const float* fvol_cl, const float* packed, const float* freq,
+                         const float* phase, const float* cam2world, const cnerf_rng* rng, float* pixels,
+                         float* depth, const cnerf_aux* aux, void* workspace, void* stream_) {
+    g_err[0] = 0;
+    if (int rc = check_cfg(cfg, true)) return rc;
+    if (!fvol_cl || !packed || !cam2world || !pixels || !depth || !workspace) return fail(CNERF_EINVAL, "render_forward: NULL argument");
+    const PackedLayout pl = packed_layout(cfg);
+    if (pl.n_film && (!freq || !phase)) return fail(CNERF_EINVAL, "render_forward: FiLM layers need freq and phase");
+    const bool hier = cfg->flags & CNERF_F_HIERARCHICAL;
+    static const cnerf_rng no_rng = {nullptr, nullptr, nullptr, nullptr};
+    if (!rng) rng = &no_rng;
+    if (hier && !rng->u_fine) return fail(CNERF_EINVAL, "render_forward: hierarchical sampling needs rng.u_fine");
+    hipStream_t stream = (hipStream_t)stream_;
+
+    const long long P = (long long)cfg->R * cfg->R, S = cfg->S;
+    const long long npi = P * S;
+    const size_t N = (size_t)cfg->B * npi;
+    char* ws = (char*)workspace;
+    float* c_rs = (float*)ws; ws += align256(N * 4 * sizeof(float));
+    float* f_rs = (float*)ws; ws += align256(N * 4 * sizeof(float));
+    float* c_z = (float*)ws;  ws += align256(N * sizeof(float));
+    float* f_z = (float*)ws;
+    if (aux) {   // write straight into the caller's buffers where given
+        if (aux->coarse_rgb_sigma) c_rs = aux->coarse_rgb_sigma;
+        if (aux->fine_rgb_sigma) f_rs = aux->fine_rgb_sigma;
+        if (aux->coarse_z) c_z = aux->coarse_z;
+        if (aux->fine_z) f_z = aux->fine_z;
+    }
+
+    FieldArgs fa;
+    fill_field_args(fa, cfg, fvol_cl, packed, freq, phase);
+    set_points(fa, cfg->B, npi);
+    fa.cam2world = cam2world;
+    // 1. coarse pass
+    fa.mode = FIELD_MODE_COARSE;
+    fa.u_strat = rng->u_strat;
+    fa.rgb_sigma = c_rs;
+    fa.z_out = c_z;
+    fa.points_out = aux ? aux->coarse_points : nullptr;
+    auto mark = [&](int i) {
+        if (aux && aux->field_events[i]) (void)hipEventRecord((hipEvent_t)aux->field_events[i], stream);
+    };
+    mark(0);
+    if (hipError_t e = launch_field(fa, cfg->H, stream)) return hip_fail(e, "field kernel (coarse)");
+    mark(1);
+
+    if (hier) {
+        // 2. coarse weights -> inverse-CDF depths
+        ResampleArgs ra{c_z, nullptr, c_rs, rng->eps_coarse, rng->u_fine, f_z, aux ? aux->inds : nullptr,
+                        aux ? aux->cdf : nullptr, aux ? aux->coarse_weights : nullptr, (long long)cfg->B * P, (int)S,
+                        cfg->noise_std, cfg->flags};
+        if (hipError_t e = launch_resample(ra, stream)) return hip_fail(e, "resample");
+        // 3. fine pass
+        fa.mode = FIELD_MODE_FINE;
+        fa.u_strat = nullptr;
+        fa.fine_z = f_z;
+        fa.rgb_sigma = f_rs;
+        fa.z_out = nullptr;
+        fa.points_out = nullptr;
+        mark(2);
+        if (hipError_t e = launch_field(fa, cfg->H, stream)) return hip_fail(e, "field kernel (fine)");
+        mark(3);
+    }
+    // 4. merge + composite + epilogue
+    MergeArgs ma{c_rs, c_z, hier ? f_rs : nullptr, hier ? f_z : nullptr, rng->eps_final, pixels, depth,
+                 aux ? aux->sort_idx : nullptr, aux ? aux->final_weights : nullptr, (long long)cfg->B * P, (int)S,
+                 make_geom(cfg), cfg->noise_std, cfg->flags};
+    if (hipError_t e = launch_merge_composite(ma, stream)) return hip_fail(e, "merge_composite");
+    return CNERF_OK;
+}
+
+}  // extern "C"

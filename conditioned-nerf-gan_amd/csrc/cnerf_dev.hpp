@@ -1,0 +1,160 @@
+// Device-side helpers shared by the gfx950 kernels of libcnerf_hip.so.
+//
+// Arithmetic contract (see DESIGN.md "Numerics"): every translation unit is compiled with -ffp-contract=off, so
+// `a * b + c` is two roundings exactly as the ATen CPU elementwise ops the reference runs, and a fused multiply-add
+// happens only where fmaf() is written -- which is where the reference's CPU path itself fuses (torch.linspace, the
+// 4x4 bmm, the 3-vector norm; verified bit-for-bit against the golden vectors).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace cnerf {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int WAVE = 64;
+
+// ---------------------------------------------------------------------------------------------------------------
+// sin(x) for |x| up to a few 1e4: two-term Cody-Waite reduction by pi (fused), odd degree-9 polynomial on
+// [-pi/2, pi/2], sign from the parity of the quotient.  Max error 1.2e-7 abs / 1.9 ulp on [-300, 300] (the
+// FiLM arguments are |freq*x+phase| < ~200).  13 VALU ops, no transcendental unit, no branches.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sin_pi_reduced(float x) {
+    const float n = __builtin_rintf(x * 0.31830987334251404f);
+    float r = __builtin_fmaf(-n, 3.1415927410125732f, x);
+    r = __builtin_fmaf(-n, -8.742277657347586e-08f, r);
+    const float s = r * r;
+    float p = 2.629978780532838e-06f;
+    p = __builtin_fmaf(p, s, -0.00019821235036943108f);
+    p = __builtin_fmaf(p, s, 0.008333230391144753f);
+    p = __builtin_fmaf(p, s, -0.1666666567325592f);
+    const float y = __builtin_fmaf(r * s, p, r);
+    const uint32_t flip = ((uint32_t)(int32_t)n) << 31;
+    return __uint_as_float(__float_as_uint(y) ^ flip);
+}
+
+// torch.linspace(start, end, steps)[i] in float32, as ATen computes it (symmetric halves, fused).
+__device__ __forceinline__ float linspace_at(float start, float end, int steps, int i) {
+    if (steps == 1) return start;
+    const float step = (end - start) / (float)(steps - 1);
+    return (i < steps / 2) ? __builtin_fmaf(step, (float)i, start) : __builtin_fmaf(-step, (float)(steps - 1 - i), end);
+}
+
+// F.softplus(x) with beta=1, threshold=20
+__device__ __forceinline__ float softplus20(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// ---------------------------------------------------------------------------------------------------------------
+// wave-wide scans in double (ATen's CPU cumsum/cumprod accumulate float32 inputs in double and round each prefix
+// to float32; a double tree scan reproduces that rounding regardless of association up to ~1e-16)
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_incl_prod(double v, int lane) {
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+        const double o = __shfl_up(v, d, WAVE);
+        if (lane >= d) v *= o;
+    }
+    return v;
+}
+__device__ __forceinline__ double wave_incl_sum(double v, int lane) {
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+        const double o = __shfl_up(v, d, WAVE);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int d = WAVE / 2; d >= 1; d >>= 1) v += __shfl_xor(v, d, WAVE);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// rays and sample points (volumetric_rendering.py:73-199, generators.py:138-142)
+// ---------------------------------------------------------------------------------------------------------------
+struct RayGeom {
+    int R, S;
+    float focal;  // 1 / tan(fov/2), computed on the host like the reference does
+    float ray_start, ray_end;
+};
+
+// unit camera-space direction of pixel (row, col)
+__device__ __forceinline__ void camera_dir(const RayGeom& g, int row, int col, float& dx, float& dy, float& dz) {
+    const float x = linspace_at(-1.0f, 1.0f, g.R, col);
+    const float y = linspace_at(-1.0f, 1.0f, g.R, row);
+    const float z = g.focal;
+    float n2 = x * x;
+    n2 = __builtin_fmaf(y, y, n2);
+    n2 = __builtin_fmaf(z, z, n2);
+    const float n = __builtin_sqrtf(n2);
+    dx = x / n;
+    dy = y / n;
+    dz = z / n;
+}
+
+// coarse sample s of a ray: jittered distance zj and world position (px,py,pz).  m = cam2world row-major (16 floats).
+__device__ __forceinline__ void coarse_sample(const RayGeom& g, const float* __restrict__ m, float dx, float dy,
+                                              float dz, int s, float u, float& zj, float& px, float& py, float& pz) {
+    const float zl = linspace_at(g.ray_start, g.ray_end, g.S, s);
+    const float dz01 = linspace_at(g.ray_start, g.ray_end, g.S, 1) - linspace_at(g.ray_start, g.ray_end, g.S, 0);
+    const float off = (u - 0.5f) * dz01;
+    zj = zl + off;
+    const float cx = dx * zl + off * dx;
+    const float cy = dy * zl + off * dy;
+    const float cz = dz * zl + off * dz;
+    px = __builtin_fmaf(m[2], cz, __builtin_fmaf(m[1], cy, m[0] * cx)) + m[3];
+    py = __builtin_fmaf(m[6], cz, __builtin_fmaf(m[5], cy, m[4] * cx)) + m[7];
+    pz = __builtin_fmaf(m[10], cz, __builtin_fmaf(m[9], cy, m[8] * cx)) + m[11];
+}
+
+// fine sample at distance t along the world-space ray: origin + rot(dir) * t
+__device__ __forceinline__ void fine_sample(const float* __restrict__ m, float dx, float dy, float dz, float t,
+                                            float& px, float& py, float& pz) {
+    const float wx = __builtin_fmaf(m[2], dz, __builtin_fmaf(m[1], dy, m[0] * dx));
+    const float wy = __builtin_fmaf(m[6], dz, __builtin_fmaf(m[5], dy, m[4] * dx));
+    const float wz = __builtin_fmaf(m[10], dz, __builtin_fmaf(m[9], dy, m[8] * dx));
+    px = m[3] + wx * t;
+    py = m[7] + wy * t;
+    pz = m[11] + wz * t;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// trilinear lookup geometry (siren.py:555-567 -> ATen grid_sampler_3d, bilinear / border / align_corners=False)
+// ---------------------------------------------------------------------------------------------------------------
+struct Corner8 {
+    int base[8];   // voxel index (iz*V + iy)*V + ix of each corner, clamped in range
+    float w[8];    // its weight; corners in ATen accumulation order: x fastest, then y, then z
+};
+
+__device__ __forceinline__ void unnormalize(float p, float half_voxel, int V, int& i0, float& lo, float& hi) {
+    const float gco = p / half_voxel;
+    float ic = ((gco + 1.0f) * (float)V - 1.0f) / 2.0f;
+    ic = fminf(fmaxf(ic, 0.0f), (float)(V - 1));
+    const float fl = floorf(ic);
+    i0 = (int)fl;
+    lo = ic - fl;
+    hi = (fl + 1.0f) - ic;
+}
+
+__device__ __forceinline__ void trilinear_corners(float px, float py, float pz, float half_voxel, int V, Corner8& c) {
+    int ix, iy, iz;
+    float lx, hx, ly, hy, lz, hz;
+    unnormalize(px, half_voxel, V, ix, lx, hx);
+    unnormalize(py, half_voxel, V, iy, ly, hy);
+    unnormalize(pz, half_voxel, V, iz, lz, hz);
+    const int ix1 = min(ix + 1, V - 1), iy1 = min(iy + 1, V - 1), iz1 = min(iz + 1, V - 1);
+    // a +1 corner that would fall at index V only occurs with weight exactly 0 (coordinate clamped to V-1), so
+    // re-reading the clamped voxel adds +0 where ATen skips the term.
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int xx = (k & 1) ? ix1 : ix, yy = (k & 2) ? iy1 : iy, zz = (k & 4) ? iz1 : iz;
+        const float wx = (k & 1) ? lx : hx, wy = (k & 2) ? ly : hy, wz = (k & 4) ? lz : hz;
+        c.base[k] = (zz * V + yy) * V + xx;
+        c.w[k] = wx * wy * wz;
+    }
+}
+
+}  // namespace cnerf

@@ -1,0 +1,106 @@
+// Internal interface between the C-ABI translation unit and the kernel translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/cnerf.h"
+#include "cnerf_dev.hpp"
+
+namespace cnerf {
+
+enum { FIELD_MODE_POINTS = 0, FIELD_MODE_COARSE = 1, FIELD_MODE_FINE = 2 };
+
+// Arguments of field_tile_kernel (passed by value).
+struct FieldArgs {
+    const float* fvol;       // (B,V,V,V,32) channel-last
+    const float* packed;     // packed weights (float4 stream, see field_kernel.hip)
+    const float* bias;       // biases of all layers then the head, inside the packed buffer
+    const float* freq;       // (B, film_stride) or null
+    const float* phase;
+    const float* points;     // mode POINTS: (B,n,3)
+    const float* cam2world;  // (B,16)
+    const float* u_strat;    // mode COARSE: (B,n) or null
+    const float* fine_z;     // mode FINE: (B,n)
+    float* rgb_sigma;        // (B,n,4)
+    float* z_out;            // mode COARSE: (B,n)
+    float* points_out;       // optional (B,n,3)
+    float* feat_out;         // optional (B,n,32)
+    long long n_per_image;
+    long long tiles_per_image;
+    long long total_tiles;
+    RayGeom geom;
+    float half_voxel;
+    int V;
+    int L;
+    int film_stride;
+    uint32_t flags;
+    int mode;
+    int layer_kind[CNERF_MAX_LAYERS];
+};
+
+hipError_t launch_pack_matrix(const float* w, int n_out, int K, int OT, float* dst, hipStream_t stream);
+hipError_t launch_field(const FieldArgs& a, int H, hipStream_t stream);
+
+// ray_kernels.hip
+struct CompositeArgs {
+    const float* rgb_sigma;  // (rays,n,4)
+    const float* z;          // (rays,n)
+    const float* eps;        // (rays,n) or null
+    float* rgb;              // (rays,3) or null
+    float* dist;             // (rays) or null
+    float* weights;          // (rays,n) or null
+    long long rays;
+    int n;
+    float noise_std;
+    uint32_t flags;
+};
+hipError_t launch_composite(const CompositeArgs& a, hipStream_t stream);
+
+struct ResampleArgs {
+    const float* z;        // (rays,S)
+    const float* weights;  // (rays,S) or null when rgb_sigma is given
+    const float* rgb_sigma;  // (rays,S,4): if non-null the coarse weights are composited here first
+    const float* eps;      // (rays,S) or null
+    const float* u;        // (rays,S)
+    float* fine_z;         // (rays,S)
+    int32_t* inds;         // optional
+    float* cdf;            // optional (rays,S-1)
+    float* weights_out;    // optional (rays,S)
+    long long rays;
+    int S;
+    float noise_std;
+    uint32_t flags;
+};
+hipError_t launch_resample(const ResampleArgs& a, hipStream_t stream);
+
+struct MergeArgs {
+    const float* coarse_rgb_sigma;  // (rays,S,4)
+    const float* coarse_z;          // (rays,S)
+    const float* fine_rgb_sigma;    // (rays,S,4) or null (non-hierarchical)
+    const float* fine_z;            // (rays,S)   or null
+    const float* eps;               // (rays,n) or null, n = 2S or S
+    float* pixels;                  // (B,3,R,R)
+    float* depth;                   // (B,R,R)
+    int32_t* sort_idx;              // optional (rays,2S)
+    float* final_weights;           // optional (rays,n)
+    long long rays;
+    int S;
+    RayGeom geom;
+    float noise_std;
+    uint32_t flags;
+};
+hipError_t launch_merge_composite(const MergeArgs& a, hipStream_t stream);
+
+hipError_t launch_transpose_cl(int B, int C, int V, const float* src, float* dst, bool to_channel_last, hipStream_t stream);
+
+struct GatherArgs {
+    const float* fvol;    // (B,V,V,V,C)
+    const float* points;  // (B,n,3)
+    float* feat;          // (B,n,C)
+    long long n_per_image;
+    int B, V, C;
+    float half_voxel;
+};
+hipError_t launch_gather(const GatherArgs& a, hipStream_t stream);
+
+}  // namespace cnerf

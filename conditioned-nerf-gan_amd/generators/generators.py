@@ -1,0 +1,77 @@
+"""ImplicitGenerator3d: the generator API of the reference (generators/generators.py:9-197), backed by the gfx950
+render path.  Same constructor, attributes, forward signature and state-dict keys, so the reference's
+train.py / inference.py / extract_shapes.py call sites work unchanged:
+
+    pixels, depth_map = generator(z, cam2worlds, img_size, fov, ray_start, ray_end, num_steps,
+                                  hierarchical_sample, **metadata)
+"""
+import torch
+import torch.nn as nn
+
+from . import siren
+from .. import ops
+
+
+class ImplicitGenerator3d(nn.Module):
+    def __init__(self, siren_type, z_dim, input_dim, output_dim, hidden_dim, drop_out=0):
+        super().__init__()
+        self.z_dim = z_dim
+        field_cls = getattr(siren, siren_type)
+        self.siren = field_cls(z_dim=z_dim, input_dim=input_dim, output_dim=output_dim, hidden_dim=hidden_dim,
+                               drop_out=drop_out, device=None)
+        self.epoch = 0
+        self.step = 0
+        self.device = None
+
+    def set_device(self, device):
+        self.device = device
+        self.siren.device = device
+
+    def forward(self, z, cam2worlds, img_size, fov, ray_start, ray_end, num_steps, hierarchical_sample, **kwargs):
+        """z: feature volume (B,C,V,V,V) or (feature volume, global feature (B,z_dim)).
+        kwargs read: clamp_mode, nerf_noise (required, like the reference), white_back, last_back; every other key
+        of the splatted metadata dict is ignored.  `_rng` (dict of tensors) injects the four random draws and
+        `_aux` (dict) receives intermediates, `_field_events` (4 hipEvent_t handles) times the field kernel -- test and
+        benchmark hooks the reference does not have.
+        Returns pixels (B,3,R,R) = 2*rgb-1 and depth_map (B,R,R)."""
+        net = self.siren
+        net.check_supported()
+        clamp_mode, noise_std = kwargs["clamp_mode"], kwargs["nerf_noise"]
+        white_back, last_back = kwargs.get("white_back", False), kwargs.get("last_back", False)
+        fvol, glob = net.split_z(z)
+        B, R, S = cam2worlds.shape[0], int(img_size), int(num_steps)
+        dev = cam2worlds.device
+        freq, phase = net.film(glob)
+        rng = kwargs.get("_rng")
+        if rng is None:
+            # same draws, shapes and order as the reference, so the torch generator advances
+            # identically; the noise tensors are drawn even when nerf_noise == 0 (volumetric_rendering.py:39)
+            P = R * R
+            rng = {"u_strat": torch.rand((B, P, S, 1), device=dev)}
+            if hierarchical_sample:
+                eps_c = torch.randn((B, P, S, 1), device=dev)
+                rng["u_fine"] = torch.rand((B * P, S), device=dev)
+                eps_f = torch.randn((B, P, 2 * S, 1), device=dev)
+                if noise_std != 0:
+                    rng["eps_coarse"], rng["eps_final"] = eps_c, eps_f
+            else:
+                eps_f = torch.randn((B, P, S, 1), device=dev)
+                if noise_std != 0:
+                    rng["eps_final"] = eps_f
+        aux_out = kwargs.get("_aux")
+        pixels, depth, aux = ops.render_forward(net, fvol, freq, phase, cam2worlds, R, fov, ray_start, ray_end, S,
+                                        bool(hierarchical_sample), clamp_mode, noise_std, white_back, last_back, rng,
+                                        want_aux=aux_out is not None, field_events=kwargs.get("_field_events"))
+        if aux_out is not None:
+            aux_out.update(aux)
+        return pixels, depth
+
+    def generate_avg_frequencies(self):
+        """Mean FiLM frequencies / phase shifts over 10000 random latents (generators.py:189-197)."""
+        zs = torch.randn((10000, self.z_dim), device=self.siren.device)
+        with torch.no_grad():
+            fo = self.siren.mapping_network(zs)
+        half = fo.shape[-1] // 2
+        self.avg_frequencies = fo[..., :half].mean(0, keepdim=True)
+        self.avg_phase_shifts = fo[..., half:].mean(0, keepdim=True)
+        return self.avg_frequencies, self.avg_phase_shifts

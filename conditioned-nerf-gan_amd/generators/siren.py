@@ -1,0 +1,156 @@
+"""Field networks of the render path: parameter holders with the reference's names, shapes and initialisation
+(generators/siren.py), evaluated by the fused gfx950 kernel through the C ABI (cnerf_field_forward /
+cnerf_render_forward).  One table describes every supported variant; the classes are generated from it, so
+`getattr(siren, siren_type)` (generators.py:15 in the reference) keeps working and reference checkpoints load
+(state-dict keys network.{i}.layer.*, network.{i}.fc1/fc2.*, final_layer.*, mapping_network.*).
+"""
+import math
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+
+VOXEL_LENGTH = 1.2  # siren.py:555 of the reference: the voxel grid spans the 1.2^3 cube
+
+
+@dataclass(frozen=True)
+class FieldSpec:
+    layers: Tuple[str, ...]     # "film" | "sine" | "res"                      (siren.py:146-230)
+    init_freq: float            # frequency_init(f): U(+-sqrt(6/in)/f)          (siren.py:134-143)
+    sigmoid_rgb: bool           # _sigmoid_rgb on the head                      (siren.py:1227-1234)
+    has_global: bool            # z = (feature_volume, global_feature)
+    input_is_zdim: bool = False  # the dRes family overrides input_dim = z_dim  (siren.py:349)
+
+
+FIELD_SPECS = {
+    "SHORTSIREN_FG": FieldSpec(("film",) * 4, 12, True, True),
+    "TALLSIREN_FG": FieldSpec(("film",) * 8, 25, True, True),
+    "DOUBLESIREN_FG": FieldSpec(("film",) * 2, 12, True, True),
+    "SingleSIREN_dg": FieldSpec(("film",), 25, False, True),
+    "SHORTSIREN_F": FieldSpec(("sine",) * 4, 12, True, False),
+    "SHORTSIREN_FRes": FieldSpec(("sine", "res", "sine"), 12, True, False),
+    "TALLSIREN_dRes": FieldSpec(("sine", "res", "res", "sine"), 25, False, False, True),
+    "TALLSIREN_dResLong": FieldSpec(("sine",) + ("res",) * 4 + ("sine",), 25, False, False, True),
+}
+
+
+class _LinearSine(nn.Module):
+    """Holder for one FiLM / plain-sine layer: `.layer` is the nn.Linear, like FiLMLayer / SirenLayer."""
+
+    def __init__(self, n_in, n_out, drop_out_prob=0):
+        super().__init__()
+        self.layer = nn.Linear(n_in, n_out)
+        self.dropout_layer = nn.Dropout(drop_out_prob)
+        self.drop_out_prob = drop_out_prob
+
+
+class FiLMLayer(_LinearSine):
+    kind = "film"
+
+
+class SirenLayer(_LinearSine):
+    kind = "sine"
+
+
+class ResSirenBlock(nn.Module):
+    """Holder for sin(x + fc2(sin(fc1 x))) (siren.py:218-230)."""
+    kind = "res"
+
+    def __init__(self, hidden_dim):
+        super().__init__()
+        self.fc1 = nn.Linear(hidden_dim, hidden_dim)
+        self.fc2 = nn.Linear(hidden_dim, hidden_dim)
+
+
+def _uniform_weights(module: nn.Module, bound_of_fan_in):
+    with torch.no_grad():
+        for m in module.modules():
+            if isinstance(m, nn.Linear):
+                b = bound_of_fan_in(m.weight.size(-1))
+                m.weight.uniform_(-b, b)
+
+
+class FieldNetwork(nn.Module):
+    """Base of every generated variant.  `forward(points, z, img_size, num_steps)` is the siren sub-API
+    (extract_shapes.py:63-69): points (B,N,3) world -> rgb_sigma (B,N,4)."""
+
+    spec: FieldSpec = None
+    variant: str = None
+
+    def __init__(self, input_dim=3, z_dim=100, hidden_dim=256, output_dim=4, drop_out=0, device=None, **kwargs):
+        super().__init__()
+        spec = self.spec
+        if spec.input_is_zdim:
+            input_dim = z_dim
+        self.device = device
+        self.input_dim, self.z_dim, self.hidden_dim, self.output_dim = input_dim, z_dim, hidden_dim, output_dim
+        self.drop_out = drop_out
+        # construction order = the reference's, so the same torch seed yields the same parameters
+        blocks = []
+        for i, kind in enumerate(spec.layers):
+            n_in = input_dim if i == 0 else hidden_dim
+            if kind == "film":
+                blocks.append(FiLMLayer(n_in, hidden_dim, drop_out))
+            elif kind == "sine":
+                blocks.append(SirenLayer(n_in, hidden_dim, drop_out))
+            else:
+                blocks.append(ResSirenBlock(hidden_dim))
+        self.network = nn.ModuleList(blocks)
+        self.final_layer = nn.Linear(hidden_dim, 4)
+        if spec.has_global:
+            self.mapping_network = nn.Linear(z_dim, len(self.network) * hidden_dim * 2)
+        f = spec.init_freq
+        _uniform_weights(self.network, lambda n: math.sqrt(6 / n) / f)
+        _uniform_weights(self.final_layer, lambda n: math.sqrt(6 / n) / f)
+        _uniform_weights(self.network[0], lambda n: 1 / n)   # first_layer_film_sine_init (siren.py:40-44)
+
+    # -- pieces the renderer needs -------------------------------------------------------------------------------
+    def split_z(self, z):
+        """-> (feature_volume (B,C,V,V,V), global_feature or None)."""
+        if self.spec.has_global:
+            fvol, glob = z
+            return fvol, glob
+        if isinstance(z, (tuple, list)):
+            return z[0], None
+        return z, None
+
+    def film(self, global_feature: Optional[torch.Tensor]):
+        """freq, phase (B, n_film*H), freq already *15+30 (siren.py:645-650).  Stays in PyTorch (tiny GEMM, K6)."""
+        if not self.spec.has_global:
+            return None, None
+        fo = self.mapping_network(global_feature)
+        half = fo.shape[-1] // 2
+        return (fo[..., :half] * 15 + 30).contiguous(), fo[..., half:].contiguous()
+
+    def field_params(self):
+        """Flat list of raw parameter tensors in the order ops.pack_field expects."""
+        out = []
+        for blk in self.network:
+            if isinstance(blk, ResSirenBlock):
+                out += [blk.fc1.weight, blk.fc1.bias, blk.fc2.weight, blk.fc2.bias]
+            else:
+                out += [blk.layer.weight, blk.layer.bias]
+        out += [self.final_layer.weight, self.final_layer.bias]
+        return out
+
+    def check_supported(self):
+        if self.drop_out and self.training:
+            raise NotImplementedError("drop_out > 0 in training mode is not supported by the HIP render path")
+
+    def forward(self, points, z, img_size=None, num_steps=None):
+        self.check_supported()
+        fvol, glob = self.split_z(z)
+        freq, phase = self.film(glob)
+        return ops.field_forward(self, fvol, freq, phase, points)
+
+
+def _make(name):
+    return type(name, (FieldNetwork,), {"spec": FIELD_SPECS[name], "variant": name, "__doc__": f"{name} field network"})
+
+
+for _n in FIELD_SPECS:
+    globals()[_n] = _make(_n)
+del _n

@@ -1,0 +1,161 @@
+/*
+ * cnerf.h -- C ABI of libcnerf_hip.so: the MI355X (gfx950) render path of the conditioned-NeRF GAN.
+ *
+ * The reference has no FFI layer; its boundary for this path is the Python generator API
+ *   generators/generators.py:33-187   ImplicitGenerator3d.forward(z, cam2worlds, img_size, fov, ...)
+ *   generators/siren.py:637-668       <SIREN variant>.forward(points, z, img_size, num_steps)
+ * Each entry point below names the reference code it replaces.  Conventions:
+ *   - every pointer is a DEVICE pointer on the current HIP device unless the comment says "host";
+ *   - nothing is allocated, freed or synchronised here: the caller passes every buffer, including the
+ *     workspace sized by cnerf_workspace_bytes(), and a stream (hipStream_t passed as void*);
+ *   - all launches go to that stream; calls are re-entrant, there is no global state;
+ *   - return value: 0 on success, a negative CNERF_E* code otherwise; never throws.
+ *   - rays: P = R*R per image, pixel p = row*R + col; points per pass N = P*S per image.
+ */
+#ifndef CNERF_H
+#define CNERF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CNERF_ABI_VERSION 1
+
+#define CNERF_OK 0
+#define CNERF_EINVAL (-22)  /* bad argument / unsupported shape (message via cnerf_last_error) */
+#define CNERF_ENOSYS (-38)  /* feature not built into this library */
+#define CNERF_ELAUNCH (-5)  /* the HIP runtime refused a launch */
+
+#define CNERF_MAX_LAYERS 16
+
+/* cnerf_cfg.flags */
+#define CNERF_F_HIERARCHICAL (1u << 0) /* generators.py:110  coarse pass + importance resampling + fine pass */
+#define CNERF_F_WHITE_BACK (1u << 1)   /* volumetric_rendering.py:59  rgb += 1 - sum(w) */
+#define CNERF_F_LAST_BACK (1u << 2)    /* volumetric_rendering.py:53  w[last] += 1 - sum(w) */
+#define CNERF_F_SOFTPLUS (1u << 3)     /* clamp_mode == "softplus" (else "relu"), volumetric_rendering.py:41-44 */
+#define CNERF_F_SIGMOID_RGB (1u << 4)  /* siren.py:1227-1234  sigmoid on channels 0..2 of the head */
+
+/* layer kinds of the field network (siren.py:146-230) */
+#define CNERF_LAYER_FILM 0 /* y = sin(freq * (W x + b) + phase), freq/phase per image */
+#define CNERF_LAYER_SINE 1 /* y = sin(W x + b) */
+#define CNERF_LAYER_RES 2  /* y = sin(x + W2 sin(W1 x + b1) + b2) */
+
+typedef struct cnerf_cfg {
+    int32_t B;            /* images in this call */
+    int32_t R;            /* img_size */
+    int32_t S;            /* num_steps (coarse samples per ray) */
+    int32_t V;            /* feature volume side */
+    int32_t C;            /* feature channels = input width of layer 0 (32) */
+    int32_t H;            /* hidden width (multiple of 32, <= 256) */
+    int32_t L;            /* number of entries in layer_kind */
+    int32_t layer_kind[CNERF_MAX_LAYERS];
+    float ray_start;      /* forward(ray_start) */
+    float ray_end;        /* forward(ray_end) */
+    float voxel_length;   /* 1.2, siren.py:555 */
+    float noise_std;      /* kwargs["nerf_noise"] */
+    uint32_t flags;       /* CNERF_F_* */
+    double fov_deg;       /* forward(fov), degrees; kept in double because the reference takes tan() of the
+                             Python float before rounding the focal length to fp32 (volumetric_rendering.py:85-87) */
+} cnerf_cfg;
+
+/* Raw parameters of the field network, exactly as the nn.Module holds them (row-major [out][in]).
+ * For a RES layer i: w[i]/b[i] = fc1, w2[i]/b2[i] = fc2.  Replaces the state the reference keeps in
+ * siren.network[i].layer.{weight,bias} / .fc1 / .fc2 and siren.final_layer (siren.py:611-625). */
+typedef struct cnerf_field_params {
+    const float* w[CNERF_MAX_LAYERS];
+    const float* b[CNERF_MAX_LAYERS];
+    const float* w2[CNERF_MAX_LAYERS];
+    const float* b2[CNERF_MAX_LAYERS];
+    const float* w_final; /* [4][H] */
+    const float* b_final; /* [4] */
+} cnerf_field_params;
+
+/* The four random tensors the reference draws, in its draw order; any may be NULL:
+ *   u_strat    (B,P,S)   uniform, stratified jitter          volumetric_rendering.py:106  (NULL -> 0.5, no jitter)
+ *   eps_coarse (B,P,S)   normal, density noise, coarse pass  volumetric_rendering.py:39   (NULL -> 0)
+ *   u_fine     (B,P,S)   uniform, inverse-CDF draws          volumetric_rendering.py:319  (required if hierarchical)
+ *   eps_final  (B,P,S')  normal, final pass, S' = 2S or S    volumetric_rendering.py:39   (NULL -> 0)
+ * eps_final is indexed in SORTED sample order, as the reference adds its noise after the merge. */
+typedef struct cnerf_rng {
+    const float* u_strat;
+    const float* eps_coarse;
+    const float* u_fine;
+    const float* eps_final;
+} cnerf_rng;
+
+/* Optional intermediate outputs (each may be NULL).  Shapes per image-major layout:
+ *   coarse_points (B,P,S,3) coarse_z (B,P,S) coarse_rgb_sigma (B,P,S,4) coarse_weights (B,P,S)
+ *   cdf (B,P,S-1) inds (B,P,S) int32   fine_z (B,P,S) fine_rgb_sigma (B,P,S,4)
+ *   sort_idx (B,P,2S) int32 (index into cat[fine, coarse])   final_weights (B,P,S') */
+typedef struct cnerf_aux {
+    float* coarse_points;
+    float* coarse_z;
+    float* coarse_rgb_sigma;
+    float* coarse_weights;
+    float* cdf;
+    int32_t* inds;
+    float* fine_z;
+    float* fine_rgb_sigma;
+    int32_t* sort_idx;
+    float* final_weights;
+    /* Optional profiling hooks (HOST handles): hipEvent_t created by the caller, recorded on the call's stream
+     * immediately before / after the field kernel of the coarse pass ([0],[1]) and of the fine pass ([2],[3]).
+     * NULL entries are skipped.  bench.py uses them to time the dominant kernel inside the timed region. */
+    void* field_events[4];
+} cnerf_aux;
+
+int cnerf_abi_version(void);
+/* Host string describing the last error raised on the calling thread ("" if none). */
+const char* cnerf_last_error(void);
+
+/* Validates cfg and returns the byte sizes the caller must provide:
+ *   packed   : packed field weights written by cnerf_pack_field
+ *   fvol_cl  : channel-last copy of the feature volume written by cnerf_fvol_channel_last
+ *   fwd_ws   : scratch of cnerf_render_forward */
+int cnerf_workspace_bytes(const cnerf_cfg* cfg, size_t* packed, size_t* fvol_cl, size_t* fwd_ws);
+
+/* (B,C,V,V,V) channel-first, as unet3d emits it (generators/unet3d.py) -> (B,V,V,V,C) channel-last, so that one
+ * trilinear corner is one contiguous C*4-byte line.  Replaces the layout F.grid_sample reads (siren.py:561-567). */
+int cnerf_fvol_channel_last(int32_t B, int32_t C, int32_t V, const float* fvol_cf, float* fvol_cl, void* stream);
+/* Transpose of the above (used for the gradient of the feature volume). */
+int cnerf_fvol_channel_first(int32_t B, int32_t C, int32_t V, const float* fvol_cl, float* fvol_cf, void* stream);
+
+/* Re-orders nn.Linear weights into MFMA A-operand order (see DESIGN.md "packed weights").  params is a HOST struct
+ * of device pointers. */
+int cnerf_pack_field(const cnerf_cfg* cfg, const cnerf_field_params* params, float* packed, void* stream);
+
+/* Trilinear lookup only: points (B,n,3) world -> feat (B,n,C).  Replaces F.grid_sample + permute
+ * (siren.py:555-571, K4/K5 of SURVEY.md 2.1).  This is the unfused "sample pass" kernel the HBM roofline is quoted on. */
+int cnerf_gather_features(const cnerf_cfg* cfg, const float* fvol_cl, const float* points, int64_t n_per_image,
+                          float* feat, void* stream);
+
+/* Field network at explicit points: points (B,n,3) -> rgb_sigma (B,n,4).
+ * Replaces <SIREN>.forward(points, z, img_size, num_steps) (siren.py:637-668 and siblings; extract_shapes.py:63-69).
+ * freq/phase: (B, n_film*H) with freq already *15+30 (siren.py:650), NULL when the network has no FiLM layer. */
+int cnerf_field_forward(const cnerf_cfg* cfg, const float* fvol_cl, const float* packed, const float* freq,
+                        const float* phase, const float* points, int64_t n_per_image, float* rgb_sigma, void* stream);
+
+/* Alpha compositing of n samples per ray: rgb_sigma (rays,n,4), z (rays,n), eps (rays,n) or NULL ->
+ * rgb (rays,3), dist (rays), weights (rays,n) (each output may be NULL).
+ * Replaces fancy_integration (volumetric_rendering.py:18-70).  Uses cfg->noise_std and flags. */
+int cnerf_composite(const cnerf_cfg* cfg, int64_t rays, int32_t n, const float* rgb_sigma, const float* z,
+                    const float* eps, float* rgb, float* dist, float* weights, void* stream);
+
+/* Inverse-CDF resampling: z, weights, u (rays,S) -> fine_z (rays,S); optional inds (rays,S) int32, cdf (rays,S-1).
+ * Replaces generators.py:123-137 + sample_pdf (volumetric_rendering.py:297-342). */
+int cnerf_resample(int64_t rays, int32_t S, const float* z, const float* weights, const float* u, float* fine_z,
+                   int32_t* inds, float* cdf, void* stream);
+
+/* The whole path: ImplicitGenerator3d.forward (generators.py:33-187).
+ *   cam2world (B,4,4) row-major;  pixels (B,3,R,R) = 2*rgb-1;  depth (B,R,R).  aux may be NULL. */
+int cnerf_render_forward(const cnerf_cfg* cfg, const float* fvol_cl, const float* packed, const float* freq,
+                         const float* phase, const float* cam2world, const cnerf_rng* rng, float* pixels,
+                         float* depth, const cnerf_aux* aux, void* workspace, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CNERF_H */

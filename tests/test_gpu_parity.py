@@ -1,0 +1,270 @@
+"""GPU parity tests: the HIP render path (through the C ABI) against the golden vectors made from the reference and
+against the CPU oracle.  Run on an MI355X with  pytest -m gpu.
+
+Tolerances (fp32): `scaled_err` = max |a-b| / max(|b|, rms(b)) must stay below 1e-4 for rgb/sigma/pixels/depth
+(north-star gate); geometry (sample positions, jittered depths, looked-up features) is bit-exact; integer outputs
+(inds, sort_idx) are bit-exact except inside a guard band around a cdf entry / between near-equal depths, where a
+1-ulp difference upstream legitimately flips the decision -- the excluded fraction is asserted tiny.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN_NAMES, SMALL_GOLDEN, scaled_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need a GPU"
+    return torch.device("cuda:0")
+
+
+def G(x, dev):
+    return None if x is None else torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+
+
+def make_generator(g, dev):
+    import cnerf_amd
+    from cnerf_amd.generators import ImplicitGenerator3d
+    m = g.meta
+    if m["has_global"]:
+        gen = ImplicitGenerator3d(m["variant"], z_dim=m["Z"], input_dim=m["C"], output_dim=4, hidden_dim=m["H"])
+    else:
+        gen = ImplicitGenerator3d(m["variant"], z_dim=m["C"], input_dim=m["C"], output_dim=4, hidden_dim=m["H"])
+    sd = {k[len("param/"):]: torch.from_numpy(g[k]) for k in g.d.files if k.startswith("param/")}
+    gen.load_state_dict(sd, strict=True)
+    gen.to(dev)
+    gen.set_device(dev)
+    gen.eval()
+    return gen
+
+
+def render_golden(g, dev, aux=None):
+    m = g.meta
+    gen = make_generator(g, dev)
+    fvol = G(g["feature_volume"], dev)
+    z = (fvol, G(g["global_feature"], dev)) if m["has_global"] else fvol
+    rng = {k: G(g.get(k), dev) for k in ("u_strat", "eps_coarse", "u_fine", "eps_final") if g.get(k) is not None}
+    with torch.no_grad():
+        pixels, depth = gen(z, G(g["cam2worlds"], dev), m["R"], m["fov"], m["ray_start"], m["ray_end"], m["S"],
+                            m["hierarchical"], clamp_mode=m["clamp"], nerf_noise=m["noise"], white_back=m["white_back"],
+                            last_back=m["last_back"], _rng=rng, _aux=aux, batch_size=7, generator={"x": 1})
+    torch.cuda.synchronize()
+    return gen, pixels, depth
+
+
+def test_library_loaded_and_no_fallback(dev):
+    import cnerf_amd
+    assert cnerf_amd._lib.lib().cnerf_abi_version() == 1
+    from cnerf_amd.generators import ImplicitGenerator3d
+    gen = ImplicitGenerator3d("SHORTSIREN_FG", 16, 32, 4, 64)
+    with pytest.raises(cnerf_amd._lib.CnerfError):   # CPU tensors are refused, never computed on the host
+        gen.siren(torch.zeros(1, 32, 3), (torch.zeros(1, 32, 4, 4, 4), torch.zeros(1, 16)))
+
+
+def test_channel_last_round_trip(dev):
+    import cnerf_amd
+    x = torch.randn(2, 32, 9, 9, 9, device=dev)
+    cl = cnerf_amd.ops.channel_last(x)
+    assert torch.equal(cl, x.permute(0, 2, 3, 4, 1).contiguous())
+    assert torch.equal(cnerf_amd.ops.channel_first(cl), x)
+
+
+@pytest.mark.parametrize("name", SMALL_GOLDEN)
+def test_trilinear_lookup_bit_exact(golden, dev, name):
+    """Unfused gather kernel == F.grid_sample of the reference, bit for bit (same corner order, no fma)."""
+    import cnerf_amd
+    g = golden(name)
+    gen = make_generator(g, dev)
+    B = g.meta["B"]
+    pts = G(g["coarse_points"], dev).reshape(B, -1, 3)
+    cl = cnerf_amd.ops.channel_last(G(g["feature_volume"], dev))
+    feat = cnerf_amd.ops.gather_features(gen.siren, cl, pts).cpu().numpy()
+    assert np.array_equal(feat, g["coarse_feat"])
+
+
+@pytest.mark.parametrize("name", GOLDEN_NAMES)
+def test_field_network(golden, dev, name):
+    """siren sub-API at the reference's own sample points: rgb and sigma within 1e-4 (scaled)."""
+    g = golden(name)
+    if "coarse_points" not in g:
+        pytest.skip("fixture stores no sample points")
+    m = g.meta
+    gen = make_generator(g, dev)
+    fvol = G(g["feature_volume"], dev)
+    z = (fvol, G(g["global_feature"], dev)) if m["has_global"] else fvol
+    pts = G(g["coarse_points"], dev).reshape(m["B"], -1, 3)
+    with torch.no_grad():
+        out = gen.siren(pts, z, m["R"], m["S"]).cpu().numpy().reshape(g["coarse_rgb_sigma"].shape)
+    ref = g["coarse_rgb_sigma"]
+    assert scaled_err(out[..., :3], ref[..., :3]) < TOL
+    assert scaled_err(out[..., 3], ref[..., 3]) < TOL
+
+
+@pytest.mark.parametrize("name", SMALL_GOLDEN)
+def test_composite_stage(golden, dev, name):
+    """fancy_integration stage fed with the reference's own rgb_sigma: weights within 1e-5."""
+    import cnerf_amd
+    g = golden(name)
+    m = g.meta
+    if not m["hierarchical"]:
+        pytest.skip("no coarse weights stored")
+    B, P, S = g["coarse_z"].shape
+    eps = g.get("eps_coarse")
+    rgb, dist, w = cnerf_amd.ops.composite(G(g["coarse_rgb_sigma"], dev).reshape(B * P, S, 4), G(g["coarse_z"], dev).reshape(B * P, S),
+                                           G(eps, dev).reshape(B * P, S) if eps is not None else None, m["noise"], m["clamp"])
+    assert scaled_err(w.cpu().numpy().reshape(B, P, S), g["coarse_weights"]) < 1e-5
+    assert torch.all(w.sum(-1) <= 1 + 1e-5)
+
+
+def flips_outside_band(cdf, u, mine, ref, band):
+    bad = mine != ref
+    robust = (np.abs(u[..., :, None] - cdf[..., None, :]) > band).all(-1)
+    return int((bad & robust).sum()), float(bad.mean())
+
+
+def bin_mass(cdf, inds):
+    """cdf[above] - cdf[below] of each draw: the denominator of the inverse-CDF interpolation.  Where it is tiny the
+    interpolated depth is ill-conditioned: a 1-ulp change of a cdf entry (the reference's own fp32 `sum` changes by
+    that much between AVX2 and AVX-512 hosts) moves the depth by ulp/den of a bin width."""
+    S = cdf.shape[-1] + 1
+    below = np.clip(inds.astype(np.int64) - 1, 0, None)
+    above = np.clip(inds.astype(np.int64), None, S - 2)
+    return np.take_along_axis(cdf, above, -1) - np.take_along_axis(cdf, below, -1)
+
+
+@pytest.mark.parametrize("name", SMALL_GOLDEN)
+def test_resample_stage(golden, dev, name):
+    """sample_pdf stage fed with the reference's own weights: bin indices bit-exact (outside a 2e-6 guard band
+    around cdf entries), fine depths within 1e-5."""
+    import cnerf_amd
+    g = golden(name)
+    if not g.meta["hierarchical"]:
+        pytest.skip("not hierarchical")
+    B, P, S = g["coarse_z"].shape
+    fine, inds, cdf = cnerf_amd.ops.resample(G(g["coarse_z"], dev).reshape(B * P, S), G(g["coarse_weights"], dev).reshape(B * P, S),
+                                             G(g["u_fine"], dev).reshape(B * P, S))
+    cdf = cdf.cpu().numpy().reshape(B, P, S - 1)
+    assert scaled_err(cdf, g["cdf"]) < 1e-6
+    hard, frac = flips_outside_band(g["cdf"], g["u_fine"], inds.cpu().numpy().reshape(B, P, S), g["inds"].astype(np.int32), 2e-6)
+    assert hard == 0 and frac < 1e-3
+    same = inds.cpu().numpy().reshape(B, P, S) == g["inds"]
+    fz = fine.cpu().numpy().reshape(B, P, S)
+    well = same & (bin_mass(g["cdf"], g["inds"]) > 1e-2)
+    assert well.mean() > 0.9
+    assert scaled_err(fz[well], g["fine_z"][well]) < 1e-5
+    # everywhere else the draw still lands inside the same bin
+    assert np.abs(fz[same] - g["fine_z"][same]).max() < 2 * (g.meta["ray_end"] - g.meta["ray_start"]) / (S - 1)
+
+
+@pytest.mark.parametrize("name", GOLDEN_NAMES)
+def test_render_end_to_end(golden, dev, name):
+    """ImplicitGenerator3d.forward with the reference's random draws injected."""
+    g = golden(name)
+    m = g.meta
+    aux = {}
+    _, pixels, depth = render_golden(g, dev, aux)
+    aux = {k: v.cpu().numpy() for k, v in aux.items()}
+    # geometry: bit-exact
+    if "coarse_points" in g:
+        assert np.array_equal(aux["coarse_points"], g["coarse_points"])
+    assert np.array_equal(aux["coarse_z"], g["coarse_z"])
+    # field outputs / weights / images: 1e-4 scaled
+    assert scaled_err(aux["coarse_rgb_sigma"][..., :3], g["coarse_rgb_sigma"][..., :3]) < TOL
+    assert scaled_err(aux["coarse_rgb_sigma"][..., 3], g["coarse_rgb_sigma"][..., 3]) < TOL
+    if m["hierarchical"]:
+        hard, frac = flips_outside_band(aux["cdf"], g["u_fine"], aux["inds"], g["inds"].astype(np.int32), 2e-5)
+        assert hard == 0, "bin index differs outside the guard band"
+        assert frac < 2e-3
+        # rays whose every draw fell in the same bin AND in a bin with non-negligible mass (well-conditioned depth)
+        same = (aux["inds"] == g["inds"]).all(-1) & (bin_mass(aux["cdf"], g["inds"]) > 1e-2).all(-1)
+        assert same.mean() > 0.8
+        assert scaled_err(aux["fine_z"][same], g["fine_z"][same]) < TOL
+        assert scaled_err(aux["fine_rgb_sigma"][same][..., :3], g["fine_rgb_sigma"][same][..., :3]) < TOL
+        assert scaled_err(aux["fine_rgb_sigma"][same][..., 3], g["fine_rgb_sigma"][same][..., 3]) < TOL
+        sidx = aux["sort_idx"][same] == g["sort_idx"][same]
+        assert sidx.mean() > 0.999
+        pix_same = same.reshape(m["B"], m["R"], m["R"])
+        p, pr = pixels.cpu().numpy(), g["pixels"]
+        msk = np.broadcast_to(pix_same[:, None], p.shape)
+        assert scaled_err(p[msk], pr[msk]) < TOL
+        assert scaled_err(depth.cpu().numpy()[pix_same], g["depth"][pix_same]) < TOL
+    # whole image, every ray (a flipped bin moves one sample by one bin: still a small change of the pixel)
+    assert scaled_err(pixels.cpu().numpy(), g["pixels"]) < 5e-3
+    assert scaled_err(depth.cpu().numpy(), g["depth"]) < 5e-3
+    if "final_weights" in g:
+        assert aux["final_weights"].shape == g["final_weights"].shape
+
+
+def test_render_matches_oracle_random_inputs(dev):
+    """Fresh seeded inputs (not a stored fixture): HIP path vs the CPU oracle on identical rays and draws."""
+    import cnerf_amd
+    from cnerf_amd.generators import ImplicitGenerator3d
+    from cnerf_amd.generators.volumetric_rendering import sample_camera_positions, create_cam2world_matrix
+    from oracle import render_oracle as O
+    torch.manual_seed(123)
+    np.random.seed(123)
+    B, R, S, V, H, Z = 2, 24, 24, 20, 128, 64
+    gen = ImplicitGenerator3d("SHORTSIREN_FG", Z, 32, 4, H)
+    with torch.no_grad():
+        gen.siren.final_layer.weight[3] *= 30
+    fvol, glob = torch.randn(B, 32, V, V, V) * 0.5, torch.randn(B, Z)
+    cam = create_cam2world_matrix(sample_camera_positions("cpu", "y", 0.7, 1.5, B), "y")
+    rng = {"u_strat": torch.rand(B, R * R, S), "eps_coarse": torch.randn(B, R * R, S), "u_fine": torch.rand(B, R * R, S),
+           "eps_final": torch.randn(B, R * R, 2 * S)}
+    params = {k: v.detach() for k, v in gen.siren.state_dict().items()}
+    ref = O.render("SHORTSIREN_FG", params, fvol, glob, cam, R, 49.13, 0.25, 1.95, S, True, "softplus", 0.3, True, False,
+                   rng["u_strat"], rng["eps_coarse"], rng["u_fine"], rng["eps_final"])
+    gen.to(dev)
+    gen.set_device(dev)
+    aux = {}
+    with torch.no_grad():
+        pixels, depth = gen((fvol.to(dev), glob.to(dev)), cam.to(dev), R, 49.13, 0.25, 1.95, S, True, clamp_mode="softplus",
+                            nerf_noise=0.3, white_back=True, _rng={k: v.to(dev) for k, v in rng.items()}, _aux=aux)
+    assert torch.equal(aux["coarse_points"].cpu(), ref.aux["coarse_points"])
+    assert scaled_err(aux["coarse_rgb_sigma"].cpu().numpy(), ref.aux["coarse_rgb_sigma"].numpy()) < TOL
+    same = (aux["inds"].cpu() == ref.aux["inds"]).all(-1).numpy()
+    assert same.mean() > 0.97
+    msk = same.reshape(B, R, R)
+    assert scaled_err(depth.cpu().numpy()[msk], ref.depth.numpy()[msk]) < TOL
+    pm = np.broadcast_to(msk[:, None], (B, 3, R, R))
+    assert scaled_err(pixels.cpu().numpy()[pm], ref.pixels.numpy()[pm]) < TOL
+
+
+def test_full_size_properties(dev):
+    """BASELINE size 128x128x64 (B=1): properties that need no oracle -- weights form a sub-probability, white
+    background fills the missing mass, depth within [ray_start, ray_end]*dir_z, determinism across two runs."""
+    import cnerf_amd
+    from cnerf_amd.generators import ImplicitGenerator3d
+    torch.manual_seed(0)
+    R, S, V = 128, 64, 64
+    gen = ImplicitGenerator3d("SHORTSIREN_FG", 256, 32, 4, 256).to(dev)
+    gen.set_device(dev)
+    with torch.no_grad():
+        gen.siren.final_layer.weight[3] *= 40
+    fvol, glob = torch.randn(1, 32, V, V, V, device=dev), torch.randn(1, 256, device=dev)
+    cam = torch.eye(4, device=dev).unsqueeze(0).clone()
+    cam[0, 2, 3] = -1.0
+    rng = {"u_strat": torch.rand(1, R * R, S, device=dev), "u_fine": torch.rand(1, R * R, S, device=dev)}
+    outs = []
+    for _ in range(2):
+        aux = {}
+        with torch.no_grad():
+            px, dp = gen((fvol, glob), cam, R, 49.13, 0.25, 1.95, S, True, clamp_mode="relu", nerf_noise=0.0, white_back=True,
+                         _rng=rng, _aux=aux)
+        outs.append((px.clone(), dp.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    w = aux["final_weights"]
+    assert torch.isfinite(px).all() and torch.isfinite(dp).all()
+    assert (w >= 0).all() and (w.sum(-1) <= 1 + 1e-5).all()
+    assert (px <= 1 + 1e-5).all() and (px >= -1 - 1e-5).all()
+    assert (dp >= 0).all() and (dp <= 1.95 + 1e-4).all()
+    z = aux["fine_z"]
+    assert (z >= 0.25 - 0.02).all() and (z <= 1.95 + 0.02).all()
+    srt = torch.gather(torch.cat([aux["fine_z"], aux["coarse_z"]], -1), -1, aux["sort_idx"].long())
+    assert (srt[..., 1:] >= srt[..., :-1]).all()           # merged depths are sorted
+    assert (aux["sort_idx"].sort(-1)[0] == torch.arange(2 * S, device=dev)).all()   # and a permutation

@@ -1,0 +1,94 @@
+"""CPU-side checks of the host layer: C-ABI exports, struct layout, module/state-dict compatibility, init parity
+with the reference (same seed -> same parameters), camera helpers.  No GPU compute."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, GOLDEN_NAMES
+
+
+def test_build_and_exports():
+    import __graft_entry__ as ge
+    ge.build()
+    import cnerf_amd
+    lib = cnerf_amd._lib.lib()
+    hdr = open(os.path.join(ROOT, "include", "cnerf.h")).read()
+    declared = set(re.findall(r"\b(cnerf_[a-z_0-9]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/cnerf.h but not exported"
+    assert declared == set(cnerf_amd._lib.PROTOTYPES), "ctypes prototypes out of sync with the header"
+    assert lib.cnerf_abi_version() == 1
+
+
+def test_cfg_validation_without_gpu():
+    """Argument validation is host code: bad shapes are refused with a message, no launch is attempted."""
+    import cnerf_amd
+    L = cnerf_amd._lib
+    cfg = L.Cfg()
+    cfg.B, cfg.R, cfg.S, cfg.V, cfg.C, cfg.H, cfg.L = 1, 8, 8, 8, 32, 256, 4
+    cfg.voxel_length, cfg.fov_deg = 1.2, 30.0
+    a, b, c = ctypes.c_size_t(), ctypes.c_size_t(), ctypes.c_size_t()
+    assert L.lib().cnerf_workspace_bytes(ctypes.byref(cfg), ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)) == 0
+    n = 8 * 8 * 8
+    assert c.value >= n * 10 * 4 and b.value >= 8 ** 3 * 32 * 4
+    # packed = 32->256, 3x 256->256, head (one 32-row tile), biases
+    assert a.value >= (32 * 256 + 3 * 256 * 256 + 32 * 256 + 4 * 256 + 4) * 4
+    cfg.H = 100
+    assert L.lib().cnerf_workspace_bytes(ctypes.byref(cfg), ctypes.byref(a), None, None) == -22
+    assert b"H=100" in L.lib().cnerf_last_error()
+    cfg.H, cfg.S = 256, 1
+    assert L.lib().cnerf_workspace_bytes(ctypes.byref(cfg), ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)) == -22
+    with pytest.raises(L.CnerfError):
+        L.ptr(torch.zeros(3))          # CPU tensors never reach the kernels
+
+
+@pytest.mark.parametrize("name", GOLDEN_NAMES)
+def test_init_and_state_dict_match_reference(golden, name):
+    """Same torch seed -> same parameters as the reference's module (network / mapping untouched by the fixture's head
+    scaling), and the reference's state-dict loads with strict=True."""
+    from cnerf_amd.generators import ImplicitGenerator3d
+    g = golden(name)
+    m = g.meta
+    torch.manual_seed(m["seed"])
+    if m["has_global"]:
+        gen = ImplicitGenerator3d(m["variant"], z_dim=m["Z"], input_dim=m["C"], output_dim=4, hidden_dim=m["H"])
+    else:
+        gen = ImplicitGenerator3d(m["variant"], z_dim=m["C"], input_dim=m["C"], output_dim=4, hidden_dim=m["H"])
+    sd = gen.state_dict()
+    ref = {k[len("param/"):]: g[k] for k in g.d.files if k.startswith("param/")}
+    assert set(sd) == set(ref)
+    for k, v in sd.items():
+        assert tuple(v.shape) == ref[k].shape
+        if "final_layer" not in k:
+            assert np.array_equal(v.numpy(), ref[k]), k
+    gen.load_state_dict({k: torch.from_numpy(v) for k, v in ref.items()}, strict=True)
+    assert gen.step == 0 and gen.epoch == 0 and hasattr(gen, "siren")
+
+
+def test_camera_helpers():
+    from cnerf_amd.generators.volumetric_rendering import sample_camera_positions, create_cam2world_matrix
+    np.random.seed(0)
+    o = sample_camera_positions("cpu", "y", 0.7, 1.5, 16)
+    r = o.norm(dim=-1)
+    assert ((r >= 0.7 - 1e-6) & (r <= 1.5 + 1e-6)).all()
+    m = create_cam2world_matrix(o, "y")
+    rot = m[:, :3, :3]
+    assert torch.allclose(rot @ rot.transpose(1, 2), torch.eye(3).expand(16, 3, 3), atol=1e-5)
+    assert torch.allclose(m[:, :3, 3], o)
+    fwd = rot[:, :, 2]                       # camera looks at the world origin
+    assert torch.allclose(fwd, -o / r.unsqueeze(-1), atol=1e-5)
+
+
+def test_unknown_variant_and_dropout():
+    from cnerf_amd.generators import ImplicitGenerator3d
+    with pytest.raises(AttributeError):
+        ImplicitGenerator3d("TALLSIREN_dg", 8, 32, 4, 64)      # a name the reference's configs still mention
+    gen = ImplicitGenerator3d("SHORTSIREN_FG", 8, 32, 4, 64, drop_out=0.1)
+    gen.train()
+    with pytest.raises(NotImplementedError):
+        gen.siren.check_supported()
