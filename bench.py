@@ -77,7 +77,8 @@ def cpu_baseline(args, gen_cpu):
     cam = torch.eye(4).unsqueeze(0).clone()
     cam[0, 2, 3] = -1.0
     params = {k: v.detach() for k, v in gen_cpu.siren.state_dict().items()}
-    cores = os.cpu_count() or 1
+    # a 1-GPU box grants a 16-core share of the host (more threads than that only oversubscribe it)
+    cores = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16)
     torch.set_num_threads(cores)
     times = []
     with torch.no_grad():

@@ -25,11 +25,12 @@ class FieldParams(C.Structure):
 
 
 class Rng(C.Structure):
-    _fields_ = [("u_strat", C.c_void_p), ("eps_coarse", C.c_void_p), ("u_fine", C.c_void_p), ("eps_final", C.c_void_p)]
+    _fields_ = [("u_strat", C.c_void_p), ("eps_coarse", C.c_void_p), ("u_fine", C.c_void_p), ("eps_final", C.c_void_p),
+                ("fine_z", C.c_void_p)]
 
 
 AUX_FIELDS = ("coarse_points", "coarse_z", "coarse_rgb_sigma", "coarse_weights", "cdf", "inds", "fine_z",
-              "fine_rgb_sigma", "sort_idx", "final_weights")
+              "fine_rgb_sigma", "sort_idx", "final_weights", "fine_points")
 
 
 class Aux(C.Structure):

@@ -49,7 +49,8 @@ int check_cfg(const cnerf_cfg* c, bool need_render) {
     return CNERF_OK;
 }
 
-// packed layout: [float4 weight stream][biases of every layer in order (RES: b1 then b2)][head bias (4)]
+// packed layout: [float4 weight stream][biases of every layer in order (RES: b1 then b2)][head bias (4)][ones H][zeros H]
+// (ones/zeros: a plain sine layer runs as a FiLM layer with freq = 1, phase = 0)
 struct PackedLayout {
     size_t weight_floats;
     size_t bias_floats;
@@ -97,6 +98,7 @@ void fill_field_args(FieldArgs& a, const cnerf_cfg* c, const float* fvol_cl, con
     a.freq = pl.n_film ? freq : nullptr;
     a.phase = pl.n_film ? phase : nullptr;
     a.film_stride = pl.n_film * c->H;
+    a.bias_floats = (int)pl.bias_floats;
     a.geom = make_geom(c);
     a.half_voxel = c->voxel_length / 2.0f;
     a.V = c->V;
@@ -123,7 +125,7 @@ int cnerf_workspace_bytes(const cnerf_cfg* cfg, size_t* packed, size_t* fvol_cl,
     g_err[0] = 0;
     if (int rc = check_cfg(cfg, fwd_ws != nullptr)) return rc;
     const PackedLayout pl = packed_layout(cfg);
-    if (packed) *packed = align256((pl.weight_floats + pl.bias_floats) * sizeof(float));
+    if (packed) *packed = align256((pl.weight_floats + pl.bias_floats + 2 * (size_t)cfg->H) * sizeof(float));
     if (fvol_cl) *fvol_cl = align256((size_t)cfg->B * cfg->V * cfg->V * cfg->V * cfg->C * sizeof(float));
     if (fwd_ws) {
         const size_t N = (size_t)cfg->B * cfg->R * cfg->R * cfg->S;
@@ -175,6 +177,9 @@ int cnerf_pack_field(const cnerf_cfg* cfg, const cnerf_field_params* p, float* p
     if (!p->w_final || !p->b_final) return fail(CNERF_EINVAL, "pack_field: head is NULL");
     if (hipError_t e = launch_pack_matrix(p->w_final, 4, H, 1, wdst, stream)) return hip_fail(e, "pack_matrix");
     if (hipError_t e = hipMemcpyAsync(bdst, p->b_final, 4 * sizeof(float), hipMemcpyDeviceToDevice, stream)) return hip_fail(e, "bias copy");
+    bdst += 4;
+    if (hipError_t e = launch_fill(bdst, 1.0f, H, stream)) return hip_fail(e, "fill");
+    if (hipError_t e = launch_fill(bdst + H, 0.0f, H, stream)) return hip_fail(e, "fill");
     return CNERF_OK;
 }
 
@@ -232,7 +237,7 @@ int cnerf_render_forward(const cnerf_cfg* cfg, const float* fvol_cl, const float
     const PackedLayout pl = packed_layout(cfg);
     if (pl.n_film && (!freq || !phase)) return fail(CNERF_EINVAL, "render_forward: FiLM layers need freq and phase");
     const bool hier = cfg->flags & CNERF_F_HIERARCHICAL;
-    static const cnerf_rng no_rng = {nullptr, nullptr, nullptr, nullptr};
+    static const cnerf_rng no_rng = {nullptr, nullptr, nullptr, nullptr, nullptr};
     if (!rng) rng = &no_rng;
     if (hier && !rng->u_fine) return fail(CNERF_EINVAL, "render_forward: hierarchical sampling needs rng.u_fine");
     hipStream_t stream = (hipStream_t)stream_;
@@ -278,10 +283,11 @@ int cnerf_render_forward(const cnerf_cfg* cfg, const float* fvol_cl, const float
         // 3. fine pass
         fa.mode = FIELD_MODE_FINE;
         fa.u_strat = nullptr;
+        if (rng->fine_z) f_z = const_cast<float*>(rng->fine_z);   // teacher-forced depths (read only from here on)
         fa.fine_z = f_z;
         fa.rgb_sigma = f_rs;
         fa.z_out = nullptr;
-        fa.points_out = nullptr;
+        fa.points_out = aux ? aux->fine_points : nullptr;
         mark(2);
         if (hipError_t e = launch_field(fa, cfg->H, stream)) return hip_fail(e, "field kernel (fine)");
         mark(3);

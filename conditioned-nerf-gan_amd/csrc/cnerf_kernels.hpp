@@ -24,7 +24,6 @@ struct FieldArgs {
     float* rgb_sigma;        // (B,n,4)
     float* z_out;            // mode COARSE: (B,n)
     float* points_out;       // optional (B,n,3)
-    float* feat_out;         // optional (B,n,32)
     long long n_per_image;
     long long tiles_per_image;
     long long total_tiles;
@@ -33,11 +32,13 @@ struct FieldArgs {
     int V;
     int L;
     int film_stride;
+    int bias_floats;         // biases of all layers + head (padded to 4): ones[H], zeros[H] follow
     uint32_t flags;
     int mode;
     int layer_kind[CNERF_MAX_LAYERS];
 };
 
+hipError_t launch_fill(float* dst, float value, int n, hipStream_t stream);
 hipError_t launch_pack_matrix(const float* w, int n_out, int K, int OT, float* dst, hipStream_t stream);
 hipError_t launch_field(const FieldArgs& a, int H, hipStream_t stream);
 

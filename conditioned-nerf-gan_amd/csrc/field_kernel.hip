@@ -61,29 +61,62 @@ __device__ __forceinline__ f32x16 load_chan16(const float* __restrict__ p, int t
     return r;
 }
 
-// one output tile: acc = init; acc += W[tile t, :] * X   over KT input tiles held in x[]
-template <int KT>
-__device__ __forceinline__ f32x16 mfma_tile(const f32x4* __restrict__ wp /* points at tile t */, const f32x16* x,
-                                            f32x16 acc, int lane) {
+// ---------------------------------------------------------------------------------------------------------------
+// One matrix product of the MLP for a 32-point tile:  out[t] = epilogue( bias[t] + W[t, :] * in )  for the OT output
+// tiles of 32 channels, KT input tiles.  The A operands (packed weights, 16 B per lane per 4 k-steps) stream from L2
+// through a ring of RING float4 registers that runs RING groups (= 4*RING MFMAs = 256*RING cycles) ahead of the MFMA
+// that consumes them, across output-tile boundaries and epilogues, so the L2 latency is hidden behind the matrix pipe.
+// Everything is unrolled: register indices of the ring, the B operands and the accumulators are compile-time.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int RING = 6;
+
+// epilogue kinds
+enum { EPI_FILM = 0, EPI_FILM_RES = 1 };
+
+template <int OT, int KT, int EPI>
+__device__ __forceinline__ void mlp_matrix(const f32x4* __restrict__ wp, const float* __restrict__ bias,
+                                           const float* __restrict__ freq, const float* __restrict__ phase,
+                                           const f32x16* in, const f32x16* res, f32x16* out, int lane, int h) {
+    constexpr int NG = OT * KT * 4;
+    f32x4 ring[RING];
 #pragma unroll
-    for (int tk = 0; tk < KT; ++tk) {
+    for (int i = 0; i < RING; ++i)
+        if (i < NG) ring[i] = wp[i * 64 + lane];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 a = wp[(tk * 4 + g) * 64 + lane];
+    for (int t = 0; t < OT; ++t) {
+        f32x16 acc = load_chan16(bias, t, h);
+        const f32x16 fr = load_chan16(freq, t, h);
+        const f32x16 ph = load_chan16(phase, t, h);
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], x[tk][4 * g + e], acc, 0, 0, 0);
+        for (int tk = 0; tk < KT; ++tk) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int idx = (t * KT + tk) * 4 + g;
+                const f32x4 a = ring[idx % RING];
+                if (idx + RING < NG) ring[idx % RING] = wp[(idx + RING) * 64 + lane];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], in[tk][4 * g + e], acc, 0, 0, 0);
+            }
         }
+        f32x16 y;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float pre = acc[r];
+            if (EPI == EPI_FILM_RES) pre = res[t][r] + pre;
+            y[r] = sin_pi_reduced(fr[r] * pre + ph[r]);
+        }
+        out[t] = y;
     }
-    return acc;
 }
 
-template <int NT>
+template <int NT, bool HAS_RES>
 __global__ __launch_bounds__(256) void field_tile_kernel(FieldArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave_in_block = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
-    const int H = NT * 32;
+    constexpr int H = NT * 32;
+    constexpr size_t TILE4 = 4 * 64;   // float4 per (t, tk) pair
 
     // XCD-aware tile ownership: blocks b and b+8 share an XCD (round-robin dispatch), so give each of the 8 block
     // classes one contiguous eighth of the tiles (a band of neighbouring rays -> a compact slab of the feature grid in
@@ -137,90 +170,63 @@ __global__ __launch_bounds__(256) void field_tile_kernel(FieldArgs a) {
         trilinear_corners(px, py, pz, a.half_voxel, a.V, cr);
         const float* vol = a.fvol + (size_t)b * a.V * a.V * a.V * 32 + 4 * h;
         f32x16 feat;
+        {
+            f32x4 q[8][4];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) feat[r] = 0.0f;
+            for (int k = 0; k < 8; ++k) {
+                const float* cp = vol + (size_t)cr.base[k] * 32;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const float* cp = vol + (size_t)cr.base[k] * 32;
-            const float wk = cr.w[k];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 q = *reinterpret_cast<const f32x4*>(cp + 8 * g);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) feat[4 * g + e] = feat[4 * g + e] + q[e] * wk;
+                for (int g = 0; g < 4; ++g) q[k][g] = *reinterpret_cast<const f32x4*>(cp + 8 * g);
             }
-        }
-        if (a.feat_out && valid) {
-            float* fo = a.feat_out + ((size_t)b * a.n_per_image + nn) * 32 + 4 * h;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                f32x4 q;
+            for (int r = 0; r < 16; ++r) feat[r] = 0.0f;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) q[e] = feat[4 * g + e];
-                *reinterpret_cast<f32x4*>(fo + 8 * g) = q;
-            }
+            for (int k = 0; k < 8; ++k)     // ATen order: corners sequentially, product and sum rounded separately
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) feat[4 * g + e] = feat[4 * g + e] + q[k][g][e] * cr.w[k];
         }
 
         // ---- MLP ---------------------------------------------------------------------------------------------------
-        Act<NT> x;      // current activations = B operands of the next layer
-        Act<NT> y;      // layer output under construction
+        // A plain sine layer is a FiLM layer with freq = 1, phase = 0 (1*x and +0 are exact): one code path.
+        Act<NT> x, y;
         const f32x4* wp = reinterpret_cast<const f32x4*>(a.packed);
         const float* bias = a.bias;              // concatenated biases, layer after layer (H each, RES: 2H)
+        const float* ones = a.bias + a.bias_floats;
+        const float* zeros = ones + H;
         const float* freq = a.freq ? a.freq + (size_t)b * a.film_stride : nullptr;
         const float* phase = a.phase ? a.phase + (size_t)b * a.film_stride : nullptr;
-
-        for (int l = 0; l < a.L; ++l) {
+        {
+            const bool film = a.layer_kind[0] == CNERF_LAYER_FILM;
+            mlp_matrix<NT, 1, EPI_FILM>(wp, bias, film ? freq : ones, film ? phase : zeros, &feat, nullptr, x.v, lane, h);
+            wp += (size_t)NT * TILE4;
+            bias += H;
+            if (film) {
+                freq += H;
+                phase += H;
+            }
+        }
+        for (int l = 1; l < a.L; ++l) {
             const int kind = a.layer_kind[l];
-            const bool first = (l == 0);
-            if (kind != CNERF_LAYER_RES) {
-                // y = sin(freq * (W x + b) + phase)   or   sin(W x + b)
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    f32x16 acc = load_chan16(bias, t, h);
-                    if (first)
-                        acc = mfma_tile<1>(wp + (size_t)t * 1 * 4 * 64, &feat, acc, lane);
-                    else
-                        acc = mfma_tile<NT>(wp + (size_t)t * NT * 4 * 64, x.v, acc, lane);
-                    if (kind == CNERF_LAYER_FILM) {
-                        const f32x16 fr = load_chan16(freq, t, h);
-                        const f32x16 ph = load_chan16(phase, t, h);
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) acc[r] = sin_pi_reduced(fr[r] * acc[r] + ph[r]);
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) acc[r] = sin_pi_reduced(acc[r]);
-                    }
-                    y.v[t] = acc;
-                }
-                wp += (size_t)NT * (first ? 1 : NT) * 4 * 64;
+            if (!HAS_RES || kind != CNERF_LAYER_RES) {
+                const bool film = kind == CNERF_LAYER_FILM;
+                mlp_matrix<NT, NT, EPI_FILM>(wp, bias, film ? freq : ones, film ? phase : zeros, x.v, nullptr, y.v, lane, h);
+                wp += (size_t)NT * NT * TILE4;
                 bias += H;
-                if (kind == CNERF_LAYER_FILM) {
+                if (film) {
                     freq += H;
                     phase += H;
                 }
 #pragma unroll
                 for (int t = 0; t < NT; ++t) x.v[t] = y.v[t];
             } else {
-                // y = sin(x + W2 sin(W1 x + b1) + b2)        (never the first layer: its input width is H)
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    f32x16 acc = load_chan16(bias, t, h);
-                    acc = mfma_tile<NT>(wp + (size_t)t * NT * 4 * 64, x.v, acc, lane);
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[r] = sin_pi_reduced(acc[r]);
-                    y.v[t] = acc;
-                }
-                wp += (size_t)NT * NT * 4 * 64;
+                // y = sin(W1 x + b1);  x = sin(x + W2 y + b2)   (tile t of x is dead once its own residual is added)
+                mlp_matrix<NT, NT, EPI_FILM>(wp, bias, ones, zeros, x.v, nullptr, y.v, lane, h);
+                wp += (size_t)NT * NT * TILE4;
                 bias += H;
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    f32x16 acc = load_chan16(bias, t, h);
-                    acc = mfma_tile<NT>(wp + (size_t)t * NT * 4 * 64, y.v, acc, lane);
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[r] = sin_pi_reduced(x.v[t][r] + acc[r]);
-                    x.v[t] = acc;   // tile t of x is dead once its own residual has been added
-                }
-                wp += (size_t)NT * NT * 4 * 64;
+                mlp_matrix<NT, NT, EPI_FILM_RES>(wp, bias, ones, zeros, y.v, x.v, x.v, lane, h);
+                wp += (size_t)NT * NT * TILE4;
                 bias += H;
             }
         }
@@ -236,7 +242,23 @@ __global__ __launch_bounds__(256) void field_tile_kernel(FieldArgs a) {
                 acc[2] = bias[2];
                 acc[3] = bias[3];
             }
-            acc = mfma_tile<NT>(wp, x.v, acc, lane);
+            constexpr int NG = NT * 4;
+            f32x4 ring[RING];
+#pragma unroll
+            for (int i = 0; i < RING; ++i)
+                if (i < NG) ring[i] = wp[i * 64 + lane];
+#pragma unroll
+            for (int tk = 0; tk < NT; ++tk) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int idx = tk * 4 + g;
+                    const f32x4 aw = ring[idx % RING];
+                    if (idx + RING < NG) ring[idx % RING] = wp[(idx + RING) * 64 + lane];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[e], x.v[tk][4 * g + e], acc, 0, 0, 0);
+                }
+            }
             if (valid && h == 0) {
                 f32x4 o;
                 if (a.flags & CNERF_F_SIGMOID_RGB) {
@@ -258,6 +280,16 @@ __global__ __launch_bounds__(256) void field_tile_kernel(FieldArgs a) {
 // ---------------------------------------------------------------------------------------------------------------
 // host-side launchers (called from cnerf_abi.hip)
 // ---------------------------------------------------------------------------------------------------------------
+__global__ void fill_kernel(float* dst, float value, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = value;
+}
+
+hipError_t launch_fill(float* dst, float value, int n, hipStream_t stream) {
+    hipLaunchKernelGGL(fill_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, dst, value, n);
+    return hipGetLastError();
+}
+
 hipError_t launch_pack_matrix(const float* w, int n_out, int K, int OT, float* dst, hipStream_t stream) {
     const int total = OT * (K / 32) * 4 * 64 * 4;
     const int blocks = (total + 255) / 256;
@@ -265,27 +297,29 @@ hipError_t launch_pack_matrix(const float* w, int n_out, int K, int OT, float* d
     return hipGetLastError();
 }
 
-template <int NT>
+template <int NT, bool HAS_RES>
 static hipError_t launch_field_nt(const FieldArgs& a, hipStream_t stream) {
     int dev = 0, cus = 256, per_cu = 1;
     if (hipGetDevice(&dev) != hipSuccess) dev = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, field_tile_kernel<NT>, 256, 0) != hipSuccess || per_cu < 1)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, field_tile_kernel<NT, HAS_RES>, 256, 0) != hipSuccess || per_cu < 1)
         per_cu = 1;
     long long want = (a.total_tiles + 3) / 4;
     long long cap = (long long)cus * per_cu;
     int blocks = (int)(want < cap ? want : cap);
     if (blocks < 8) blocks = 8;               // every XCD class owns an eighth of the tiles
     blocks = (blocks + 7) / 8 * 8;
-    hipLaunchKernelGGL(field_tile_kernel<NT>, dim3(blocks), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL((field_tile_kernel<NT, HAS_RES>), dim3(blocks), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 
 hipError_t launch_field(const FieldArgs& a, int H, hipStream_t stream) {
+    bool res = false;
+    for (int l = 0; l < a.L; ++l) res |= a.layer_kind[l] == CNERF_LAYER_RES;
     switch (H / 32) {
-        case 2: return launch_field_nt<2>(a, stream);
-        case 4: return launch_field_nt<4>(a, stream);
-        case 8: return launch_field_nt<8>(a, stream);
+        case 2: return res ? launch_field_nt<2, true>(a, stream) : launch_field_nt<2, false>(a, stream);
+        case 4: return res ? launch_field_nt<4, true>(a, stream) : launch_field_nt<4, false>(a, stream);
+        case 8: return res ? launch_field_nt<8, true>(a, stream) : launch_field_nt<8, false>(a, stream);
         default: return hipErrorInvalidValue;
     }
 }

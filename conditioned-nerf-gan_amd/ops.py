@@ -161,8 +161,9 @@ AUX_SHAPES = {
     "fine_rgb_sigma": lambda B, P, S, n: ((B, P, S, 4), torch.float32),
     "sort_idx": lambda B, P, S, n: ((B, P, 2 * S), torch.int32),
     "final_weights": lambda B, P, S, n: ((B, P, n), torch.float32),
+    "fine_points": lambda B, P, S, n: ((B, P, S, 3), torch.float32),
 }
-HIER_ONLY = {"coarse_weights", "cdf", "inds", "fine_z", "fine_rgb_sigma", "sort_idx"}
+HIER_ONLY = {"coarse_weights", "cdf", "inds", "fine_z", "fine_rgb_sigma", "sort_idx", "fine_points"}
 
 
 def render_forward(net, fvol, freq, phase, cam2world, img_size, fov, ray_start, ray_end, num_steps, hierarchical,
@@ -184,9 +185,9 @@ def render_forward(net, fvol, freq, phase, cam2world, img_size, fov, ray_start, 
     pixels = torch.empty((B, 3, R, R), dtype=torch.float32, device=dev)
     depth = torch.empty((B, R, R), dtype=torch.float32, device=dev)
     rng = rng or {}
-    keep = [_f32(rng.get(k)) for k in ("u_strat", "eps_coarse", "u_fine", "eps_final")]
+    keep = [_f32(rng.get(k)) for k in ("u_strat", "eps_coarse", "u_fine", "eps_final", "fine_z")]
     r = L.Rng()
-    r.u_strat, r.eps_coarse, r.u_fine, r.eps_final = [None if t is None else t.data_ptr() for t in keep]
+    r.u_strat, r.eps_coarse, r.u_fine, r.eps_final, r.fine_z = [None if t is None else t.data_ptr() for t in keep]
     for t in keep:
         L.ptr(t)   # validates device / contiguity
     aux_t, aux_s = {}, None

@@ -78,18 +78,22 @@ typedef struct cnerf_field_params {
  *   eps_coarse (B,P,S)   normal, density noise, coarse pass  volumetric_rendering.py:39   (NULL -> 0)
  *   u_fine     (B,P,S)   uniform, inverse-CDF draws          volumetric_rendering.py:319  (required if hierarchical)
  *   eps_final  (B,P,S')  normal, final pass, S' = 2S or S    volumetric_rendering.py:39   (NULL -> 0)
- * eps_final is indexed in SORTED sample order, as the reference adds its noise after the merge. */
+ * eps_final is indexed in SORTED sample order, as the reference adds its noise after the merge.
+ *   fine_z     (B,P,S)   test hook, normally NULL: depths that REPLACE the resampled ones for the fine pass and the merge
+ *                        (the resampling still runs and fills aux).  The field is chaotic in position, so parity of the
+ *                        fine pass / merge / final composite is pinned by forcing the reference's own fine depths. */
 typedef struct cnerf_rng {
     const float* u_strat;
     const float* eps_coarse;
     const float* u_fine;
     const float* eps_final;
+    const float* fine_z;
 } cnerf_rng;
 
 /* Optional intermediate outputs (each may be NULL).  Shapes per image-major layout:
  *   coarse_points (B,P,S,3) coarse_z (B,P,S) coarse_rgb_sigma (B,P,S,4) coarse_weights (B,P,S)
  *   cdf (B,P,S-1) inds (B,P,S) int32   fine_z (B,P,S) fine_rgb_sigma (B,P,S,4)
- *   sort_idx (B,P,2S) int32 (index into cat[fine, coarse])   final_weights (B,P,S') */
+ *   sort_idx (B,P,2S) int32 (index into cat[fine, coarse])   final_weights (B,P,S')   fine_points (B,P,S,3) */
 typedef struct cnerf_aux {
     float* coarse_points;
     float* coarse_z;
@@ -101,6 +105,7 @@ typedef struct cnerf_aux {
     float* fine_rgb_sigma;
     int32_t* sort_idx;
     float* final_weights;
+    float* fine_points; /* (B,P,S,3) */
     /* Optional profiling hooks (HOST handles): hipEvent_t created by the caller, recorded on the call's stream
      * immediately before / after the field kernel of the coarse pass ([0],[1]) and of the fine pass ([2],[3]).
      * NULL entries are skipped.  bench.py uses them to time the dominant kernel inside the timed region. */

@@ -81,11 +81,26 @@ def coarse_world_points(cam2world: torch.Tensor, dirs_cam: torch.Tensor, z_lin: 
     already-formed points), then the 4x4 cam2world; (B,P,S,3), dirs (B,P,3), origins (B,3)."""
     B, P, S = offset.shape
     pc = dirs_cam.reshape(1, P, 1, 3) * z_lin.reshape(1, 1, S, 1) + offset.unsqueeze(-1) * dirs_cam.reshape(1, P, 1, 3)
-    hom = torch.cat([pc, torch.ones(B, P, S, 1)], -1).reshape(B, P * S, 4)
-    pw = torch.bmm(cam2world, hom.transpose(1, 2)).transpose(1, 2).reshape(B, P, S, 4)[..., :3]
-    dirs_w = torch.bmm(cam2world[:, :3, :3], dirs_cam.reshape(1, P, 3).expand(B, P, 3).transpose(1, 2)).transpose(1, 2)
+    # The reference does these two transforms with torch.bmm (volumetric_rendering.py:168-192); its CPU BLAS evaluates
+    # each output as the k-ordered fused chain fma(m2, z, fma(m1, y, m0*x)) (+ m3): verified bit-for-bit against the
+    # golden vectors.  Spelled out here (fma emulated through float64) so that the oracle does not depend on which
+    # GEMM micro-kernel the host's BLAS picks for a 3x3 or 4x4 product.
+    m = cam2world.reshape(B, 1, 1, 4, 4)
+    pw = _fma_chain3(m[..., :3, 0], pc[..., 0:1], m[..., :3, 1], pc[..., 1:2], m[..., :3, 2], pc[..., 2:3]) + m[..., :3, 3]
+    d = dirs_cam.reshape(1, P, 3)
+    mr = cam2world.reshape(B, 1, 4, 4)
+    dirs_w = _fma_chain3(mr[..., :3, 0], d[..., 0:1], mr[..., :3, 1], d[..., 1:2], mr[..., :3, 2], d[..., 2:3])
     origins = cam2world[:, :3, 3].clone()
     return pw.contiguous(), dirs_w.contiguous(), origins
+
+
+def _fma32(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor) -> torch.Tensor:
+    """float32 fma(a, b, c): the product of two float32 is exact in float64, one rounding to float32 at the end."""
+    return (a.double() * b.double() + c.double()).float()
+
+
+def _fma_chain3(m0, x, m1, y, m2, z):
+    return _fma32(m2, z, _fma32(m1, y, m0 * x))
 
 
 # ---------------------------------------------------------------------------------------

@@ -43,20 +43,6 @@ def make_generator(g, dev):
     return gen
 
 
-def render_golden(g, dev, aux=None):
-    m = g.meta
-    gen = make_generator(g, dev)
-    fvol = G(g["feature_volume"], dev)
-    z = (fvol, G(g["global_feature"], dev)) if m["has_global"] else fvol
-    rng = {k: G(g.get(k), dev) for k in ("u_strat", "eps_coarse", "u_fine", "eps_final") if g.get(k) is not None}
-    with torch.no_grad():
-        pixels, depth = gen(z, G(g["cam2worlds"], dev), m["R"], m["fov"], m["ray_start"], m["ray_end"], m["S"],
-                            m["hierarchical"], clamp_mode=m["clamp"], nerf_noise=m["noise"], white_back=m["white_back"],
-                            last_back=m["last_back"], _rng=rng, _aux=aux, batch_size=7, generator={"x": 1})
-    torch.cuda.synchronize()
-    return gen, pixels, depth
-
-
 def test_library_loaded_and_no_fallback(dev):
     import cnerf_amd
     assert cnerf_amd._lib.lib().cnerf_abi_version() == 1
@@ -161,43 +147,69 @@ def test_resample_stage(golden, dev, name):
     assert np.abs(fz[same] - g["fine_z"][same]).max() < 2 * (g.meta["ray_end"] - g.meta["ray_start"]) / (S - 1)
 
 
+def _render_with(g, dev, forced):
+    m = g.meta
+    gen = make_generator(g, dev)
+    fvol = G(g["feature_volume"], dev)
+    z = (fvol, G(g["global_feature"], dev)) if m["has_global"] else fvol
+    rng = {k: G(g.get(k), dev) for k in ("u_strat", "eps_coarse", "u_fine", "eps_final") if g.get(k) is not None}
+    if forced:
+        rng["fine_z"] = G(g["fine_z"], dev)
+    aux = {}
+    with torch.no_grad():
+        pixels, depth = gen(z, G(g["cam2worlds"], dev), m["R"], m["fov"], m["ray_start"], m["ray_end"], m["S"],
+                            m["hierarchical"], clamp_mode=m["clamp"], nerf_noise=m["noise"], white_back=m["white_back"],
+                            last_back=m["last_back"], _rng=rng, _aux=aux, batch_size=7, generator={"x": 1})
+    torch.cuda.synchronize()
+    return pixels.cpu().numpy(), depth.cpu().numpy(), {k: v.cpu().numpy() for k, v in aux.items()}
+
+
 @pytest.mark.parametrize("name", GOLDEN_NAMES)
-def test_render_end_to_end(golden, dev, name):
-    """ImplicitGenerator3d.forward with the reference's random draws injected."""
+def test_render_teacher_forced(golden, dev, name):
+    """ImplicitGenerator3d.forward with the reference's random draws AND its resampled depths injected: every stage
+    downstream of the resampling sees the reference's own sample positions, so the whole image must agree to 1e-4
+    and the merge permutation bit for bit.  (Without forcing, the 1e-5-level rounding of the coarse densities moves
+    the fine depths by ~1e-6, and the random-init SIREN on a random volume turns that into O(1e-2) colour changes:
+    the field is chaotic in position, see test_render_free_running.)"""
     g = golden(name)
     m = g.meta
-    aux = {}
-    _, pixels, depth = render_golden(g, dev, aux)
-    aux = {k: v.cpu().numpy() for k, v in aux.items()}
-    # geometry: bit-exact
+    pixels, depth, aux = _render_with(g, dev, forced=m["hierarchical"])
     if "coarse_points" in g:
-        assert np.array_equal(aux["coarse_points"], g["coarse_points"])
+        assert np.array_equal(aux["coarse_points"], g["coarse_points"])        # geometry: bit-exact
     assert np.array_equal(aux["coarse_z"], g["coarse_z"])
-    # field outputs / weights / images: 1e-4 scaled
     assert scaled_err(aux["coarse_rgb_sigma"][..., :3], g["coarse_rgb_sigma"][..., :3]) < TOL
     assert scaled_err(aux["coarse_rgb_sigma"][..., 3], g["coarse_rgb_sigma"][..., 3]) < TOL
     if m["hierarchical"]:
-        hard, frac = flips_outside_band(aux["cdf"], g["u_fine"], aux["inds"], g["inds"].astype(np.int32), 2e-5)
-        assert hard == 0, "bin index differs outside the guard band"
-        assert frac < 2e-3
-        # rays whose every draw fell in the same bin AND in a bin with non-negligible mass (well-conditioned depth)
-        same = (aux["inds"] == g["inds"]).all(-1) & (bin_mass(aux["cdf"], g["inds"]) > 1e-2).all(-1)
-        assert same.mean() > 0.8
-        assert scaled_err(aux["fine_z"][same], g["fine_z"][same]) < TOL
-        assert scaled_err(aux["fine_rgb_sigma"][same][..., :3], g["fine_rgb_sigma"][same][..., :3]) < TOL
-        assert scaled_err(aux["fine_rgb_sigma"][same][..., 3], g["fine_rgb_sigma"][same][..., 3]) < TOL
-        sidx = aux["sort_idx"][same] == g["sort_idx"][same]
-        assert sidx.mean() > 0.999
-        pix_same = same.reshape(m["B"], m["R"], m["R"])
-        p, pr = pixels.cpu().numpy(), g["pixels"]
-        msk = np.broadcast_to(pix_same[:, None], p.shape)
-        assert scaled_err(p[msk], pr[msk]) < TOL
-        assert scaled_err(depth.cpu().numpy()[pix_same], g["depth"][pix_same]) < TOL
-    # whole image, every ray (a flipped bin moves one sample by one bin: still a small change of the pixel)
-    assert scaled_err(pixels.cpu().numpy(), g["pixels"]) < 5e-3
-    assert scaled_err(depth.cpu().numpy(), g["depth"]) < 5e-3
+        if "fine_points" in g:
+            assert np.array_equal(aux["fine_points"], g["fine_points"])
+        assert scaled_err(aux["fine_rgb_sigma"][..., :3], g["fine_rgb_sigma"][..., :3]) < TOL
+        assert scaled_err(aux["fine_rgb_sigma"][..., 3], g["fine_rgb_sigma"][..., 3]) < TOL
+        assert np.array_equal(aux["sort_idx"], g["sort_idx"].astype(np.int32))  # merge order: bit-exact
     if "final_weights" in g:
-        assert aux["final_weights"].shape == g["final_weights"].shape
+        # weights multiply up to 2S factors exp(-delta*sigma): the 1e-5-level density rounding accumulates
+        assert scaled_err(aux["final_weights"], g["final_weights"]) < 5e-4
+    assert scaled_err(pixels, g["pixels"]) < TOL
+    assert scaled_err(depth, g["depth"]) < TOL
+
+
+@pytest.mark.parametrize("name", [n for n in GOLDEN_NAMES if n != "short_fg_nohier"])
+def test_render_free_running(golden, dev, name):
+    """The same call without forcing: coarse pass as above; resampling decisions bit-exact outside a guard band of
+    1e-4 around the cdf entries (the coarse weights carry the 1e-5-level rounding of the densities); depths of draws
+    that fall into bins of non-negligible mass (> 1e-2) within 3e-3 of a bin width; images close on average."""
+    g = golden(name)
+    m = g.meta
+    pixels, depth, aux = _render_with(g, dev, forced=False)
+    assert scaled_err(aux["coarse_weights"], g["coarse_weights"]) < 5e-4
+    hard, frac = flips_outside_band(aux["cdf"], g["u_fine"], aux["inds"], g["inds"].astype(np.int32), 1e-4)
+    assert hard == 0, "bin index differs outside the guard band"
+    assert frac < 5e-3
+    well = (aux["inds"] == g["inds"]) & (bin_mass(aux["cdf"], g["inds"]) > 1e-2)
+    assert well.mean() > 0.8
+    binw = (m["ray_end"] - m["ray_start"]) / (m["S"] - 1)
+    assert np.abs(aux["fine_z"] - g["fine_z"])[well].max() < 3e-3 * binw
+    assert np.abs(pixels - g["pixels"]).mean() < 2e-3
+    assert np.abs(depth - g["depth"]).mean() < 2e-3
 
 
 def test_render_matches_oracle_random_inputs(dev):
@@ -227,12 +239,17 @@ def test_render_matches_oracle_random_inputs(dev):
                             nerf_noise=0.3, white_back=True, _rng={k: v.to(dev) for k, v in rng.items()}, _aux=aux)
     assert torch.equal(aux["coarse_points"].cpu(), ref.aux["coarse_points"])
     assert scaled_err(aux["coarse_rgb_sigma"].cpu().numpy(), ref.aux["coarse_rgb_sigma"].numpy()) < TOL
-    same = (aux["inds"].cpu() == ref.aux["inds"]).all(-1).numpy()
-    assert same.mean() > 0.97
-    msk = same.reshape(B, R, R)
-    assert scaled_err(depth.cpu().numpy()[msk], ref.depth.numpy()[msk]) < TOL
-    pm = np.broadcast_to(msk[:, None], (B, 3, R, R))
-    assert scaled_err(pixels.cpu().numpy()[pm], ref.pixels.numpy()[pm]) < TOL
+    assert (aux["inds"].cpu() == ref.aux["inds"]).float().mean() > 0.995
+    # second call with the oracle's fine depths forced: the whole image agrees
+    rng_f = {k: v.to(dev) for k, v in rng.items()}
+    rng_f["fine_z"] = ref.aux["fine_z"].to(dev)
+    with torch.no_grad():
+        pixels, depth = gen((fvol.to(dev), glob.to(dev)), cam.to(dev), R, 49.13, 0.25, 1.95, S, True, clamp_mode="softplus",
+                            nerf_noise=0.3, white_back=True, _rng=rng_f, _aux=aux)
+    assert torch.equal(aux["fine_points"].cpu(), ref.aux["fine_points"])
+    assert torch.equal(aux["sort_idx"].cpu().long(), ref.aux["sort_idx"])
+    assert scaled_err(depth.cpu().numpy(), ref.depth.numpy()) < TOL
+    assert scaled_err(pixels.cpu().numpy(), ref.pixels.numpy()) < TOL
 
 
 def test_full_size_properties(dev):
