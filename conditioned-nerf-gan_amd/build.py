@@ -21,6 +21,7 @@ def _stale(target, deps):
 
 def build_library(force=False, verbose=False, extra_flags=()):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    extra_flags = tuple(extra_flags) + tuple(os.environ.get("CNERF_EXTRA_FLAGS", "").split())
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     objs = []
     for src in SOURCES:

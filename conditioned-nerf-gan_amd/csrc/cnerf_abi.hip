@@ -267,6 +267,9 @@ int cnerf_render_forward(const cnerf_cfg* cfg, const float* fvol_cl, const float
     fa.rgb_sigma = c_rs;
     fa.z_out = c_z;
     fa.points_out = aux ? aux->coarse_points : nullptr;
+#ifdef CNERF_STAMPS
+    fa.stamps = aux ? (unsigned long long*)aux->cdf : nullptr;   // diagnostic build, non-hierarchical call: cdf slot is never written
+#endif
     auto mark = [&](int i) {
         if (aux && aux->field_events[i]) (void)hipEventRecord((hipEvent_t)aux->field_events[i], stream);
     };

@@ -24,6 +24,7 @@ struct FieldArgs {
     float* rgb_sigma;        // (B,n,4)
     float* z_out;            // mode COARSE: (B,n)
     float* points_out;       // optional (B,n,3)
+    unsigned long long* stamps;  // diagnostic builds (-DCNERF_STAMPS) only: 8 cycle totals; else unused
     long long n_per_image;
     long long tiles_per_image;
     long long total_tiles;

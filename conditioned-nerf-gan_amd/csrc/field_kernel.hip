@@ -68,50 +68,93 @@ __device__ __forceinline__ f32x16 load_chan16(const float* __restrict__ p, int t
 // that consumes them, across output-tile boundaries and epilogues, so the L2 latency is hidden behind the matrix pipe.
 // Everything is unrolled: register indices of the ring, the B operands and the accumulators are compile-time.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int RING = 6;
+#ifndef CNERF_RING
+#define CNERF_RING 6
+#endif
+constexpr int RING = CNERF_RING;
 
 // epilogue kinds
 enum { EPI_FILM = 0, EPI_FILM_RES = 1 };
 
+template <int EPI>
+__device__ __forceinline__ float epilogue_one(float acc, float res, float fr, float ph) {
+    float pre = acc;
+    if (EPI == EPI_FILM_RES) pre = res + pre;
+    return sin_pi_reduced(fr * pre + ph);
+}
+
+// Software pipeline, pinned with sched_barrier(0) at every group boundary (left alone, the scheduler turns the loop
+// nest inside out -- k outermost, all OT accumulators live, loads in bursts, every epilogue at the end of the layer):
+//   group = { 1 ring load (RING groups ahead), 4 MFMAs of output tile t, the epilogue of 16/GPT... elements of tile t-1 }
+// so the FiLM/sine VALU work of one output tile executes under the MFMAs of the next one, and only two accumulator
+// tiles are live.
 template <int OT, int KT, int EPI>
 __device__ __forceinline__ void mlp_matrix(const f32x4* __restrict__ wp, const float* __restrict__ bias,
                                            const float* __restrict__ freq, const float* __restrict__ phase,
                                            const f32x16* in, const f32x16* res, f32x16* out, int lane, int h) {
-    constexpr int NG = OT * KT * 4;
+    constexpr int GPT = KT * 4;                       // groups (of 4 MFMAs) per output tile
+    constexpr int NG = OT * GPT;
+    constexpr int EPG = GPT >= 16 ? 1 : 16 / GPT;     // epilogue elements handled per group
+    constexpr int ESTEP = GPT >= 16 ? GPT / 16 : 1;   // ... every ESTEP-th group
     f32x4 ring[RING];
 #pragma unroll
     for (int i = 0; i < RING; ++i)
         if (i < NG) ring[i] = wp[i * 64 + lane];
+    f32x16 acc_prev, fr_prev, ph_prev;
+    f32x16 bias_next = load_chan16(bias, 0, h);       // per-channel vectors are fetched one output tile ahead
 #pragma unroll
     for (int t = 0; t < OT; ++t) {
-        f32x16 acc = load_chan16(bias, t, h);
+        f32x16 acc = bias_next;
+        if (t + 1 < OT) bias_next = load_chan16(bias, t + 1, h);
         const f32x16 fr = load_chan16(freq, t, h);
         const f32x16 ph = load_chan16(phase, t, h);
 #pragma unroll
-        for (int tk = 0; tk < KT; ++tk) {
+        for (int gi = 0; gi < GPT; ++gi) {
+            const int tk = gi >> 2, g = gi & 3;
+            const int idx = t * GPT + gi;
+            const f32x4 a = ring[idx % RING];
+            if (idx + RING < NG) ring[idx % RING] = wp[(idx + RING) * 64 + lane];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int idx = (t * KT + tk) * 4 + g;
-                const f32x4 a = ring[idx % RING];
-                if (idx + RING < NG) ring[idx % RING] = wp[(idx + RING) * 64 + lane];
+            for (int e = 0; e < 4; ++e)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], in[tk][4 * g + e], acc, 0, 0, 0);
+            if (t > 0 && gi % ESTEP == 0 && gi / ESTEP < 16 / EPG) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], in[tk][4 * g + e], acc, 0, 0, 0);
+                for (int q = 0; q < EPG; ++q) {
+                    const int r = (gi / ESTEP) * EPG + q;
+                    out[t - 1][r] = epilogue_one<EPI>(acc_prev[r], EPI == EPI_FILM_RES ? res[t - 1][r] : 0.0f, fr_prev[r], ph_prev[r]);
+                }
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        f32x16 y;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float pre = acc[r];
-            if (EPI == EPI_FILM_RES) pre = res[t][r] + pre;
-            y[r] = sin_pi_reduced(fr[r] * pre + ph[r]);
-        }
-        out[t] = y;
+        acc_prev = acc;
+        fr_prev = fr;
+        ph_prev = ph;
     }
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        out[OT - 1][r] = epilogue_one<EPI>(acc_prev[r], EPI == EPI_FILM_RES ? res[OT - 1][r] : 0.0f, fr_prev[r], ph_prev[r]);
 }
+
+#ifdef CNERF_STAMPS
+// Diagnostic build only: per-phase cycle totals (s_memtime) summed over all tiles of all waves into a.stamps[0..7].
+#define STAMP(i)                                                                                     \
+    do {                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                           \
+        const unsigned long long now_ = __builtin_readcyclecounter();                                \
+        __builtin_amdgcn_sched_barrier(0);                                                           \
+        st_[i] += now_ - last_;                                                                      \
+        last_ = now_;                                                                                \
+    } while (0)
+#else
+#define STAMP(i)
+#endif
 
 template <int NT, bool HAS_RES>
 __global__ __launch_bounds__(256) void field_tile_kernel(FieldArgs a) {
+#ifdef CNERF_STAMPS
+    unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long last_ = __builtin_readcyclecounter();
+#endif
     const int lane = threadIdx.x & 63;
     const int wave_in_block = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
@@ -134,6 +177,7 @@ __global__ __launch_bounds__(256) void field_tile_kernel(FieldArgs a) {
         const bool valid = n < a.n_per_image;
         const long long nn = valid ? n : (a.n_per_image - 1);                     // padded lanes recompute the last point
 
+        STAMP(0);   // loop overhead / previous store
         // ---- sample position -------------------------------------------------------------------------------------
         float px, py, pz;
         if (a.mode == FIELD_MODE_POINTS) {
@@ -188,6 +232,8 @@ __global__ __launch_bounds__(256) void field_tile_kernel(FieldArgs a) {
                     for (int e = 0; e < 4; ++e) feat[4 * g + e] = feat[4 * g + e] + q[k][g][e] * cr.w[k];
         }
 
+        asm volatile("" :: "v"(feat[0]), "v"(feat[15]));
+        STAMP(1);   // position + gather
         // ---- MLP ---------------------------------------------------------------------------------------------------
         // A plain sine layer is a FiLM layer with freq = 1, phase = 0 (1*x and +0 are exact): one code path.
         Act<NT> x, y;
@@ -207,6 +253,8 @@ __global__ __launch_bounds__(256) void field_tile_kernel(FieldArgs a) {
                 phase += H;
             }
         }
+        asm volatile("" :: "v"(x.v[0][0]), "v"(x.v[NT - 1][15]));
+        STAMP(2);   // layer 0
         for (int l = 1; l < a.L; ++l) {
             const int kind = a.layer_kind[l];
             if (!HAS_RES || kind != CNERF_LAYER_RES) {
@@ -220,6 +268,8 @@ __global__ __launch_bounds__(256) void field_tile_kernel(FieldArgs a) {
                 }
 #pragma unroll
                 for (int t = 0; t < NT; ++t) x.v[t] = y.v[t];
+                asm volatile("" :: "v"(x.v[0][0]), "v"(x.v[NT - 1][15]));
+                STAMP(3);   // hidden layers
             } else {
                 // y = sin(W1 x + b1);  x = sin(x + W2 y + b2)   (tile t of x is dead once its own residual is added)
                 mlp_matrix<NT, NT, EPI_FILM>(wp, bias, ones, zeros, x.v, nullptr, y.v, lane, h);
@@ -257,6 +307,7 @@ __global__ __launch_bounds__(256) void field_tile_kernel(FieldArgs a) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[e], x.v[tk][4 * g + e], acc, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
             if (valid && h == 0) {
@@ -274,7 +325,12 @@ __global__ __launch_bounds__(256) void field_tile_kernel(FieldArgs a) {
                 *reinterpret_cast<f32x4*>(a.rgb_sigma + ((size_t)b * a.n_per_image + nn) * 4) = o;
             }
         }
+        STAMP(4);   // head
     }
+#ifdef CNERF_STAMPS
+    if (a.stamps && lane == 0)
+        for (int i = 0; i < 8; ++i) atomicAdd(a.stamps + i, st_[i]);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------
