@@ -86,8 +86,10 @@ __device__ __forceinline__ float epilogue_one(float acc, float res, float fr, fl
 // Software pipeline, pinned with sched_barrier(0) at every group boundary (left alone, the scheduler turns the loop
 // nest inside out -- k outermost, all OT accumulators live, loads in bursts, every epilogue at the end of the layer):
 //   group = { 1 ring load (RING groups ahead), 4 MFMAs of output tile t, the epilogue of 16/GPT... elements of tile t-1 }
-// so the FiLM/sine VALU work of one output tile executes under the MFMAs of the next one, and only two accumulator
-// tiles are live.
+// so only two accumulator tiles are live and the weight stream stays RING groups ahead.  Note (measured,
+// scripts/ubench/mfma_valu_overlap.hip): VALU instructions do NOT hide under v_mfma_f32_32x32x2_f32 -- each adds its
+// full 2 cycles whether spread between the MFMAs or clumped, with one or two accumulator chains -- so for the fp32
+// path  time = MFMA + VALU + stalls  and the epilogue placement only matters for register pressure and load distance.
 template <int OT, int KT, int EPI>
 __device__ __forceinline__ void mlp_matrix(const f32x4* __restrict__ wp, const float* __restrict__ bias,
                                            const float* __restrict__ freq, const float* __restrict__ phase,
