@@ -54,6 +54,10 @@ PROTOTYPES = {
                                  C.c_void_p, C.c_void_p]),
     "cnerf_render_forward": (C.c_int, [C.POINTER(Cfg), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.POINTER(Rng), C.c_void_p, C.c_void_p, C.POINTER(Aux), C.c_void_p, C.c_void_p]),
+    "cnerf_backward_bytes": (C.c_int, [C.POINTER(Cfg), C.POINTER(C.c_size_t)]),
+    "cnerf_pack_field_transposed": (C.c_int, [C.POINTER(Cfg), C.POINTER(FieldParams), C.c_void_p, C.c_void_p]),
+    "cnerf_merge_composite_backward": (C.c_int, [C.POINTER(Cfg)] + [C.c_void_p] * 10),
+    "cnerf_field_backward": (C.c_int, [C.POINTER(Cfg), C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 17),
 }
 
 _lib = None

@@ -303,4 +303,108 @@ int cnerf_render_forward(const cnerf_cfg* cfg, const float* fvol_cl, const float
     return CNERF_OK;
 }
 
+int cnerf_backward_bytes(const cnerf_cfg* cfg, size_t* packed_t) {
+    g_err[0] = 0;
+    if (int rc = check_cfg(cfg, false)) return rc;
+    const size_t NT = cfg->H / 32, tile = 4 * 64 * 4;
+    size_t fl = NT * 2 * 64;                                  // head^T
+    for (int l = cfg->L - 1; l >= 1; --l) fl += NT * NT * tile;
+    fl += NT * tile;                                          // layer 0 transposed: one 32-row output tile
+    if (packed_t) *packed_t = align256(fl * sizeof(float));
+    return CNERF_OK;
+}
+
+int cnerf_pack_field_transposed(const cnerf_cfg* cfg, const cnerf_field_params* p, float* packed_t, void* stream_) {
+    g_err[0] = 0;
+    if (int rc = check_cfg(cfg, false)) return rc;
+    if (!p || !packed_t) return fail(CNERF_EINVAL, "pack_field_transposed: NULL argument");
+    for (int l = 0; l < cfg->L; ++l)
+        if (cfg->layer_kind[l] == CNERF_LAYER_RES) return fail(CNERF_ENOSYS, "backward through residual blocks is not implemented");
+    hipStream_t stream = (hipStream_t)stream_;
+    const int H = cfg->H, NT = H / 32;
+    const size_t tile = 4 * 64 * 4;
+    float* dst = packed_t;
+    if (!p->w_final) return fail(CNERF_EINVAL, "pack_field_transposed: head is NULL");
+    if (hipError_t e = launch_pack_head_t(p->w_final, H, dst, stream)) return hip_fail(e, "pack_head_t");
+    dst += (size_t)NT * 2 * 64;
+    for (int l = cfg->L - 1; l >= 1; --l) {
+        if (!p->w[l]) return fail(CNERF_EINVAL, "pack_field_transposed: layer %d weight is NULL", l);
+        if (hipError_t e = launch_pack_matrix_t(p->w[l], H, H, NT, dst, stream)) return hip_fail(e, "pack_matrix_t");
+        dst += (size_t)NT * NT * tile;
+    }
+    if (!p->w[0]) return fail(CNERF_EINVAL, "pack_field_transposed: layer 0 weight is NULL");
+    if (hipError_t e = launch_pack_matrix_t(p->w[0], H, cfg->C, 1, dst, stream)) return hip_fail(e, "pack_matrix_t");
+    return CNERF_OK;
+}
+
+int cnerf_merge_composite_backward(const cnerf_cfg* cfg, const float* coarse_rgb_sigma, const float* coarse_z,
+                                   const float* fine_rgb_sigma, const float* fine_z, const float* eps_final,
+                                   const float* grad_pixels, const float* grad_depth, float* grad_coarse,
+                                   float* grad_fine, void* stream) {
+    g_err[0] = 0;
+    if (int rc = check_cfg(cfg, true)) return rc;
+    const bool hier = cfg->flags & CNERF_F_HIERARCHICAL;
+    if (!coarse_rgb_sigma || !coarse_z || !grad_pixels || !grad_coarse) return fail(CNERF_EINVAL, "merge_composite_backward: NULL argument");
+    if (hier && (!fine_rgb_sigma || !fine_z || !grad_fine)) return fail(CNERF_EINVAL, "merge_composite_backward: fine tensors missing");
+    MergeBwdArgs a{coarse_rgb_sigma, coarse_z, hier ? fine_rgb_sigma : nullptr, hier ? fine_z : nullptr, eps_final,
+                   grad_pixels, grad_depth, grad_coarse, hier ? grad_fine : nullptr,
+                   (long long)cfg->B * cfg->R * cfg->R, cfg->S, make_geom(cfg), cfg->noise_std, cfg->flags};
+    if (hipError_t e = launch_merge_composite_backward(a, (hipStream_t)stream)) return hip_fail(e, "merge_composite_backward");
+    return CNERF_OK;
+}
+
+int cnerf_field_backward(const cnerf_cfg* cfg, int32_t pass, int32_t image0, int32_t n_images, const float* fvol_cl,
+                         const float* packed, const float* packed_t, const float* freq, const float* phase,
+                         const float* cam2world, const float* u_strat, const float* fine_z,
+                         const float* grad_rgb_sigma, const float* saved_rgb_sigma, float* act_feat, float* act_h,
+                         float* act_c, float* act_g, float* act_go, float* grad_fvol_cl, void* stream_) {
+    g_err[0] = 0;
+    if (int rc = check_cfg(cfg, true)) return rc;
+    for (int l = 0; l < cfg->L; ++l)
+        if (cfg->layer_kind[l] == CNERF_LAYER_RES) return fail(CNERF_ENOSYS, "backward through residual blocks is not implemented");
+    if (image0 < 0 || n_images < 1 || image0 + n_images > cfg->B) return fail(CNERF_EINVAL, "field_backward: image range out of [0,B)");
+    if (pass < 0 || pass > 2) return fail(CNERF_EINVAL, "field_backward: pass must be 0 (coarse), 1 (fine) or 2 (explicit points)");
+    if (!fvol_cl || !packed || !packed_t || !cam2world || !grad_rgb_sigma || !saved_rgb_sigma || !act_feat || !act_h || !act_c ||
+        !act_g || !act_go || !grad_fvol_cl)
+        return fail(CNERF_EINVAL, "field_backward: NULL argument");
+    if (pass == 1 && !fine_z) return fail(CNERF_EINVAL, "field_backward: the fine pass needs fine_z");
+    const PackedLayout pl = packed_layout(cfg);
+    if (pl.n_film && (!freq || !phase)) return fail(CNERF_EINVAL, "field_backward: FiLM layers need freq and phase");
+    hipStream_t stream = (hipStream_t)stream_;
+    const long long npi = (long long)cfg->R * cfg->R * cfg->S;
+    const size_t vol = (size_t)cfg->V * cfg->V * cfg->V * 32;
+
+    FieldArgs fa;
+    fill_field_args(fa, cfg, fvol_cl + (size_t)image0 * vol, packed, pl.n_film ? freq + (size_t)image0 * pl.n_film * cfg->H : nullptr,
+                    pl.n_film ? phase + (size_t)image0 * pl.n_film * cfg->H : nullptr);
+    set_points(fa, n_images, npi);
+    fa.cam2world = cam2world + (size_t)image0 * 16;
+    if (pass == 0) {
+        fa.mode = FIELD_MODE_COARSE;
+        fa.u_strat = u_strat ? u_strat + (size_t)image0 * npi : nullptr;
+    } else if (pass == 1) {
+        fa.mode = FIELD_MODE_FINE;
+        fa.fine_z = fine_z + (size_t)image0 * npi;
+    } else {
+        if (!u_strat) return fail(CNERF_EINVAL, "field_backward: pass 2 takes the points (B,R*R*S,3) in the u_strat argument");
+        fa.mode = FIELD_MODE_POINTS;
+        fa.points = u_strat + (size_t)image0 * npi * 3;
+    }
+    fa.rgb_sigma = act_go;          // the re-run forward needs somewhere to put its head output: overwritten below by go'
+    fa.z_out = nullptr;
+    fa.act_points = (long long)n_images * npi;
+    fa.act_feat = act_feat;
+    fa.act_h = act_h;
+    fa.act_c = act_c;
+    if (hipError_t e = launch_field(fa, cfg->H, stream)) return hip_fail(e, "field kernel (activation store)");
+    fa.packed_t = packed_t;
+    fa.grad_out = grad_rgb_sigma + (size_t)image0 * npi * 4;
+    fa.saved_out = saved_rgb_sigma + (size_t)image0 * npi * 4;
+    fa.act_g = act_g;
+    fa.act_go = act_go;
+    fa.grad_fvol = grad_fvol_cl + (size_t)image0 * vol;
+    if (hipError_t e = launch_field_backward(fa, cfg->H, stream)) return hip_fail(e, "field backward kernel");
+    return CNERF_OK;
+}
+
 }  // extern "C"

@@ -25,6 +25,18 @@ struct FieldArgs {
     float* z_out;            // mode COARSE: (B,n)
     float* points_out;       // optional (B,n,3)
     unsigned long long* stamps;  // diagnostic builds (-DCNERF_STAMPS) only: 8 cycle totals; else unused
+    // activation store of the backward pass (all null in a plain forward): row-major [point][channel]
+    long long act_points;    // rows of every activation buffer (= B * n_per_image of the chunk)
+    float* act_feat;         // (n,32) looked-up features
+    float* act_h;            // (L,n,H) layer outputs sin(arg)
+    float* act_c;            // (L,n,H) cos(arg)
+    // field_backward_kernel only
+    const float* packed_t;   // transposed packed weights (cnerf_pack_field_transposed)
+    const float* grad_out;   // (n,4) d loss / d rgb_sigma
+    const float* saved_out;  // (n,4) rgb_sigma of the forward (sigmoid')
+    float* act_g;            // (L,n,H) d loss / d arg
+    float* act_go;           // (n,4)   d loss / d head pre-activation
+    float* grad_fvol;        // (V,V,V,32) of this image, accumulated with atomics
     long long n_per_image;
     long long tiles_per_image;
     long long total_tiles;
@@ -42,6 +54,9 @@ struct FieldArgs {
 hipError_t launch_fill(float* dst, float value, int n, hipStream_t stream);
 hipError_t launch_pack_matrix(const float* w, int n_out, int K, int OT, float* dst, hipStream_t stream);
 hipError_t launch_field(const FieldArgs& a, int H, hipStream_t stream);
+hipError_t launch_field_backward(const FieldArgs& a, int H, hipStream_t stream);
+hipError_t launch_pack_head_t(const float* w, int H, float* dst, hipStream_t stream);
+hipError_t launch_pack_matrix_t(const float* w, int n_rows_w, int n_cols_w, int OT, float* dst, hipStream_t stream);
 
 // ray_kernels.hip
 struct CompositeArgs {
@@ -92,6 +107,24 @@ struct MergeArgs {
     uint32_t flags;
 };
 hipError_t launch_merge_composite(const MergeArgs& a, hipStream_t stream);
+
+struct MergeBwdArgs {
+    const float* coarse_rgb_sigma;  // (rays,S,4) saved by the forward
+    const float* coarse_z;          // (rays,S)
+    const float* fine_rgb_sigma;    // (rays,S,4) or null
+    const float* fine_z;            // (rays,S)   or null
+    const float* eps;               // (rays,n) or null
+    const float* grad_pixels;       // (B,3,R,R)
+    const float* grad_depth;        // (B,R,R) or null
+    float* grad_coarse;             // (rays,S,4)
+    float* grad_fine;               // (rays,S,4) or null
+    long long rays;
+    int S;
+    RayGeom geom;
+    float noise_std;
+    uint32_t flags;
+};
+hipError_t launch_merge_composite_backward(const MergeBwdArgs& a, hipStream_t stream);
 
 hipError_t launch_transpose_cl(int B, int C, int V, const float* src, float* dst, bool to_channel_last, hipStream_t stream);
 

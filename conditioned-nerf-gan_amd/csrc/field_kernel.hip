@@ -76,11 +76,27 @@ constexpr int RING = CNERF_RING;
 // epilogue kinds
 enum { EPI_FILM = 0, EPI_FILM_RES = 1 };
 
-template <int EPI>
-__device__ __forceinline__ float epilogue_one(float acc, float res, float fr, float ph) {
+template <int EPI, bool STORE>
+__device__ __forceinline__ float epilogue_one(float acc, float res, float fr, float ph, float& cs) {
     float pre = acc;
     if (EPI == EPI_FILM_RES) pre = res + pre;
+    if (STORE) {
+        float sn;
+        sincos_pi_reduced(fr * pre + ph, sn, cs);
+        return sn;
+    }
     return sin_pi_reduced(fr * pre + ph);
+}
+
+// row-major activation store of one output tile: lane (j,h) owns channels 32t + 8g + 4h + e of its point
+__device__ __forceinline__ void store_tile_rows(float* __restrict__ row /* &buf[point][0] */, int t, int h, const f32x16& v) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        f32x4 q;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) q[e] = v[4 * g + e];
+        *reinterpret_cast<f32x4*>(row + 32 * t + 8 * g + 4 * h) = q;
+    }
 }
 
 // Software pipeline, pinned with sched_barrier(0) at every group boundary (left alone, the scheduler turns the loop
@@ -90,10 +106,11 @@ __device__ __forceinline__ float epilogue_one(float acc, float res, float fr, fl
 // scripts/ubench/mfma_valu_overlap.hip): VALU instructions do NOT hide under v_mfma_f32_32x32x2_f32 -- each adds its
 // full 2 cycles whether spread between the MFMAs or clumped, with one or two accumulator chains -- so for the fp32
 // path  time = MFMA + VALU + stalls  and the epilogue placement only matters for register pressure and load distance.
-template <int OT, int KT, int EPI>
+template <int OT, int KT, int EPI, bool STORE>
 __device__ __forceinline__ void mlp_matrix(const f32x4* __restrict__ wp, const float* __restrict__ bias,
                                            const float* __restrict__ freq, const float* __restrict__ phase,
-                                           const f32x16* in, const f32x16* res, f32x16* out, int lane, int h) {
+                                           const f32x16* in, const f32x16* res, f32x16* out, int lane, int h,
+                                           float* __restrict__ row_h, float* __restrict__ row_c) {
     constexpr int GPT = KT * 4;                       // groups (of 4 MFMAs) per output tile
     constexpr int NG = OT * GPT;
     constexpr int EPG = GPT >= 16 ? 1 : 16 / GPT;     // epilogue elements handled per group
@@ -102,7 +119,7 @@ __device__ __forceinline__ void mlp_matrix(const f32x4* __restrict__ wp, const f
 #pragma unroll
     for (int i = 0; i < RING; ++i)
         if (i < NG) ring[i] = wp[i * 64 + lane];
-    f32x16 acc_prev, fr_prev, ph_prev;
+    f32x16 acc_prev, fr_prev, ph_prev, cos_t;
     f32x16 bias_next = load_chan16(bias, 0, h);       // per-channel vectors are fetched one output tile ahead
 #pragma unroll
     for (int t = 0; t < OT; ++t) {
@@ -123,8 +140,15 @@ __device__ __forceinline__ void mlp_matrix(const f32x4* __restrict__ wp, const f
 #pragma unroll
                 for (int q = 0; q < EPG; ++q) {
                     const int r = (gi / ESTEP) * EPG + q;
-                    out[t - 1][r] = epilogue_one<EPI>(acc_prev[r], EPI == EPI_FILM_RES ? res[t - 1][r] : 0.0f, fr_prev[r], ph_prev[r]);
+                    float cs_ = 0.0f;
+                    out[t - 1][r] = epilogue_one<EPI, STORE>(acc_prev[r], EPI == EPI_FILM_RES ? res[t - 1][r] : 0.0f, fr_prev[r],
+                                                             ph_prev[r], cs_);
+                    if (STORE) cos_t[r] = cs_;
                 }
+            }
+            if (STORE && t > 0 && gi == GPT - 1) {      // tile t-1 is complete: spill it for the backward pass
+                store_tile_rows(row_h, t - 1, h, out[t - 1]);
+                store_tile_rows(row_c, t - 1, h, cos_t);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -133,8 +157,16 @@ __device__ __forceinline__ void mlp_matrix(const f32x4* __restrict__ wp, const f
         ph_prev = ph;
     }
 #pragma unroll
-    for (int r = 0; r < 16; ++r)
-        out[OT - 1][r] = epilogue_one<EPI>(acc_prev[r], EPI == EPI_FILM_RES ? res[OT - 1][r] : 0.0f, fr_prev[r], ph_prev[r]);
+    for (int r = 0; r < 16; ++r) {
+        float cs_ = 0.0f;
+        out[OT - 1][r] = epilogue_one<EPI, STORE>(acc_prev[r], EPI == EPI_FILM_RES ? res[OT - 1][r] : 0.0f, fr_prev[r], ph_prev[r],
+                                                  cs_);
+        if (STORE) cos_t[r] = cs_;
+    }
+    if (STORE) {
+        store_tile_rows(row_h, OT - 1, h, out[OT - 1]);
+        store_tile_rows(row_c, OT - 1, h, cos_t);
+    }
 }
 
 #ifdef CNERF_STAMPS
@@ -151,29 +183,69 @@ __device__ __forceinline__ void mlp_matrix(const f32x4* __restrict__ wp, const f
 #define STAMP(i)
 #endif
 
-template <int NT, bool HAS_RES>
+// sample position of point nn of image b (shared by the forward and the backward kernel)
+__device__ __forceinline__ void tile_point(const FieldArgs& a, int b, long long nn, bool valid, int h, bool write,
+                                           float& px, float& py, float& pz) {
+    if (a.mode == FIELD_MODE_POINTS) {
+        const float* p = a.points + ((size_t)b * a.n_per_image + nn) * 3;
+        px = p[0];
+        py = p[1];
+        pz = p[2];
+    } else {
+        const int S = a.geom.S, R = a.geom.R;
+        const int ray = (int)(nn / S), s = (int)(nn - (long long)ray * S);
+        const int row = ray / R, col = ray - row * R;
+        float dx, dy, dz;
+        camera_dir(a.geom, row, col, dx, dy, dz);
+        const float* m = a.cam2world + (size_t)b * 16;
+        if (a.mode == FIELD_MODE_COARSE) {
+            const float u = a.u_strat ? a.u_strat[(size_t)b * a.n_per_image + nn] : 0.5f;
+            float zj;
+            coarse_sample(a.geom, m, dx, dy, dz, s, u, zj, px, py, pz);
+            if (write && a.z_out && valid && h == 0) a.z_out[(size_t)b * a.n_per_image + nn] = zj;
+        } else {
+            const float t = a.fine_z[(size_t)b * a.n_per_image + nn];
+            fine_sample(m, dx, dy, dz, t, px, py, pz);
+        }
+    }
+    if (write && a.points_out && valid && h == 0) {
+        float* po = a.points_out + ((size_t)b * a.n_per_image + nn) * 3;
+        po[0] = px;
+        po[1] = py;
+        po[2] = pz;
+    }
+}
+
+// XCD-aware tile ownership: blocks b and b+8 share an XCD (round-robin dispatch), so give each of the 8 block classes
+// one contiguous eighth of the tiles (a band of neighbouring rays -> a compact slab of the feature grid in that XCD's
+// L2).  Placement only changes speed, never results.
+struct TileRange {
+    long long begin, end, stride;
+};
+__device__ __forceinline__ TileRange tile_range(long long total_tiles) {
+    const int nblk = gridDim.x;
+    const int cls = blockIdx.x & 7, idx_in_cls = blockIdx.x >> 3;
+    const int blk_per_cls = (nblk + 7 - cls) / 8;   // blocks whose id % 8 == cls
+    TileRange r;
+    r.begin = total_tiles * cls / 8 + idx_in_cls * 4 + (threadIdx.x >> 6);
+    r.end = total_tiles * (cls + 1) / 8;
+    r.stride = (long long)blk_per_cls * 4;
+    return r;
+}
+
+template <int NT, bool HAS_RES, bool STORE>
 __global__ __launch_bounds__(256) void field_tile_kernel(FieldArgs a) {
 #ifdef CNERF_STAMPS
     unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long last_ = __builtin_readcyclecounter();
 #endif
     const int lane = threadIdx.x & 63;
-    const int wave_in_block = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
     constexpr int H = NT * 32;
     constexpr size_t TILE4 = 4 * 64;   // float4 per (t, tk) pair
 
-    // XCD-aware tile ownership: blocks b and b+8 share an XCD (round-robin dispatch), so give each of the 8 block
-    // classes one contiguous eighth of the tiles (a band of neighbouring rays -> a compact slab of the feature grid in
-    // that XCD's L2).  Placement only changes speed, never results.
-    const int nblk = gridDim.x;
-    const int cls = blockIdx.x & 7, idx_in_cls = blockIdx.x >> 3;
-    const int blk_per_cls = (nblk + 7 - cls) / 8;   // blocks whose id % 8 == cls
-    const long long T = a.total_tiles;
-    const long long t_begin = T * cls / 8, t_end = T * (cls + 1) / 8;
-    const long long stride = (long long)blk_per_cls * 4;
-
-    for (long long tile = t_begin + idx_in_cls * 4 + wave_in_block; tile < t_end; tile += stride) {
+    const TileRange tr = tile_range(a.total_tiles);
+    for (long long tile = tr.begin; tile < tr.end; tile += tr.stride) {
         const int b = (int)(tile / a.tiles_per_image);
         const long long n = (tile - (long long)b * a.tiles_per_image) * 32 + j;  // point index inside image b
         const bool valid = n < a.n_per_image;
@@ -182,34 +254,7 @@ __global__ __launch_bounds__(256) void field_tile_kernel(FieldArgs a) {
         STAMP(0);   // loop overhead / previous store
         // ---- sample position -------------------------------------------------------------------------------------
         float px, py, pz;
-        if (a.mode == FIELD_MODE_POINTS) {
-            const float* p = a.points + ((size_t)b * a.n_per_image + nn) * 3;
-            px = p[0];
-            py = p[1];
-            pz = p[2];
-        } else {
-            const int S = a.geom.S, R = a.geom.R;
-            const int ray = (int)(nn / S), s = (int)(nn - (long long)ray * S);
-            const int row = ray / R, col = ray - row * R;
-            float dx, dy, dz;
-            camera_dir(a.geom, row, col, dx, dy, dz);
-            const float* m = a.cam2world + (size_t)b * 16;
-            if (a.mode == FIELD_MODE_COARSE) {
-                const float u = a.u_strat ? a.u_strat[(size_t)b * a.n_per_image + nn] : 0.5f;
-                float zj;
-                coarse_sample(a.geom, m, dx, dy, dz, s, u, zj, px, py, pz);
-                if (valid && h == 0) a.z_out[(size_t)b * a.n_per_image + nn] = zj;
-            } else {
-                const float t = a.fine_z[(size_t)b * a.n_per_image + nn];
-                fine_sample(m, dx, dy, dz, t, px, py, pz);
-            }
-        }
-        if (a.points_out && valid && h == 0) {
-            float* po = a.points_out + ((size_t)b * a.n_per_image + nn) * 3;
-            po[0] = px;
-            po[1] = py;
-            po[2] = pz;
-        }
+        tile_point(a, b, nn, valid, h, true, px, py, pz);
 
         // ---- trilinear lookup: this lane's 16 of the 32 channels (8g + 4h + e) ---------------------------------------
         Corner8 cr;
@@ -239,6 +284,20 @@ __global__ __launch_bounds__(256) void field_tile_kernel(FieldArgs a) {
         // ---- MLP ---------------------------------------------------------------------------------------------------
         // A plain sine layer is a FiLM layer with freq = 1, phase = 0 (1*x and +0 are exact): one code path.
         Act<NT> x, y;
+        const size_t gpt = (size_t)b * a.n_per_image + nn;                 // global point row of the activation buffers
+        const size_t act_layer = (size_t)a.act_points * H;                 // floats per layer in act_h / act_c
+        float* row_h = STORE ? a.act_h + gpt * H : nullptr;
+        float* row_c = STORE ? a.act_c + gpt * H : nullptr;
+        if (STORE) {
+            float* fo = a.act_feat + gpt * 32 + 4 * h;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 q;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) q[e] = feat[4 * g + e];
+                *reinterpret_cast<f32x4*>(fo + 8 * g) = q;
+            }
+        }
         const f32x4* wp = reinterpret_cast<const f32x4*>(a.packed);
         const float* bias = a.bias;              // concatenated biases, layer after layer (H each, RES: 2H)
         const float* ones = a.bias + a.bias_floats;
@@ -247,7 +306,12 @@ __global__ __launch_bounds__(256) void field_tile_kernel(FieldArgs a) {
         const float* phase = a.phase ? a.phase + (size_t)b * a.film_stride : nullptr;
         {
             const bool film = a.layer_kind[0] == CNERF_LAYER_FILM;
-            mlp_matrix<NT, 1, EPI_FILM>(wp, bias, film ? freq : ones, film ? phase : zeros, &feat, nullptr, x.v, lane, h);
+            mlp_matrix<NT, 1, EPI_FILM, STORE>(wp, bias, film ? freq : ones, film ? phase : zeros, &feat, nullptr, x.v, lane, h,
+                                               row_h, row_c);
+            if (STORE) {
+                row_h += act_layer;
+                row_c += act_layer;
+            }
             wp += (size_t)NT * TILE4;
             bias += H;
             if (film) {
@@ -261,7 +325,12 @@ __global__ __launch_bounds__(256) void field_tile_kernel(FieldArgs a) {
             const int kind = a.layer_kind[l];
             if (!HAS_RES || kind != CNERF_LAYER_RES) {
                 const bool film = kind == CNERF_LAYER_FILM;
-                mlp_matrix<NT, NT, EPI_FILM>(wp, bias, film ? freq : ones, film ? phase : zeros, x.v, nullptr, y.v, lane, h);
+                mlp_matrix<NT, NT, EPI_FILM, STORE>(wp, bias, film ? freq : ones, film ? phase : zeros, x.v, nullptr, y.v, lane,
+                                                    h, row_h, row_c);
+                if (STORE) {
+                    row_h += act_layer;
+                    row_c += act_layer;
+                }
                 wp += (size_t)NT * NT * TILE4;
                 bias += H;
                 if (film) {
@@ -274,10 +343,10 @@ __global__ __launch_bounds__(256) void field_tile_kernel(FieldArgs a) {
                 STAMP(3);   // hidden layers
             } else {
                 // y = sin(W1 x + b1);  x = sin(x + W2 y + b2)   (tile t of x is dead once its own residual is added)
-                mlp_matrix<NT, NT, EPI_FILM>(wp, bias, ones, zeros, x.v, nullptr, y.v, lane, h);
+                mlp_matrix<NT, NT, EPI_FILM, false>(wp, bias, ones, zeros, x.v, nullptr, y.v, lane, h, nullptr, nullptr);
                 wp += (size_t)NT * NT * TILE4;
                 bias += H;
-                mlp_matrix<NT, NT, EPI_FILM_RES>(wp, bias, ones, zeros, y.v, x.v, x.v, lane, h);
+                mlp_matrix<NT, NT, EPI_FILM_RES, false>(wp, bias, ones, zeros, y.v, x.v, x.v, lane, h, nullptr, nullptr);
                 wp += (size_t)NT * NT * TILE4;
                 bias += H;
             }
@@ -336,8 +405,209 @@ __global__ __launch_bounds__(256) void field_tile_kernel(FieldArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Backward of the point pass for one 32-point tile per wave (FiLM / sine layers; residual blocks are not supported yet).
+//
+//   go' = d loss / d head pre-activation (sigmoid' applied)                          -> act_go (n,4)
+//   g_h_L = W_head^T go'            (MFMA, K = 4 outputs in two k-steps)
+//   for l = L..1:  g_arg_l = g_h_l * cos(arg_l)   -> act_g[l] (n,H)   (the weight / FiLM gradients are GEMMs and column
+//                  g_pre_l = g_arg_l * freq_l                           sums over these buffers: done by the caller with
+//                  g_h_{l-1} = W_l^T g_pre_l   (MFMA, transposed pack)  rocBLAS, they are plain library GEMMs)
+//   g_feat (32 ch) -> trilinear scatter-add into the channel-last gradient volume with fp32 atomics; the tile is
+//   transposed through LDS so that one wave instruction adds two whole 128-byte corner lines (the shape the memory-side
+//   atomic units run at full rate for: MI355X_MICROARCH.md "Global float atomics").
+// The same chaining as the forward applies: the accumulator registers of g_h are the B operands of the next product.
+// ---------------------------------------------------------------------------------------------------------------
+template <int OT, int KT>
+__device__ __forceinline__ void bwd_matrix(const f32x4* __restrict__ wp, const f32x16* in, f32x16* out, int lane) {
+    constexpr int GPT = KT * 4;
+    constexpr int NG = OT * GPT;
+    f32x4 ring[RING];
+#pragma unroll
+    for (int i = 0; i < RING; ++i)
+        if (i < NG) ring[i] = wp[i * 64 + lane];
+#pragma unroll
+    for (int t = 0; t < OT; ++t) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+        for (int gi = 0; gi < GPT; ++gi) {
+            const int tk = gi >> 2, g = gi & 3;
+            const int idx = t * GPT + gi;
+            const f32x4 a = ring[idx % RING];
+            if (idx + RING < NG) ring[idx % RING] = wp[(idx + RING) * 64 + lane];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], in[tk][4 * g + e], acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        out[t] = acc;
+    }
+}
+
+// g_arg = g_h * cos(arg) (stored), g_pre = g_arg * freq       for all NT tiles of one layer
+template <int NT>
+__device__ __forceinline__ void bwd_activation(f32x16* g, const float* __restrict__ row_c, float* __restrict__ row_g,
+                                               const float* __restrict__ freq, int h) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        f32x16 ga;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const f32x4 c = *reinterpret_cast<const f32x4*>(row_c + 32 * t + 8 * gq + 4 * h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ga[4 * gq + e] = g[t][4 * gq + e] * c[e];
+        }
+        store_tile_rows(row_g, t, h, ga);
+        const f32x16 fr = load_chan16(freq, t, h);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) g[t][r] = ga[r] * fr[r];
+    }
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void field_backward_kernel(FieldArgs a) {
+    __shared__ float s_g[4][32][33];     // per wave: g_feat [point][channel] (padded)
+    __shared__ int s_base[4][32][8];
+    __shared__ float s_w[4][32][8];
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    constexpr int H = NT * 32;
+    constexpr size_t TILE4 = 4 * 64;
+    const TileRange tr = tile_range(a.total_tiles);
+    for (long long tile = tr.begin; tile < tr.end; tile += tr.stride) {
+        const int b = (int)(tile / a.tiles_per_image);
+        const long long n = (tile - (long long)b * a.tiles_per_image) * 32 + j;
+        const bool valid = n < a.n_per_image;
+        const long long nn = valid ? n : (a.n_per_image - 1);
+        const size_t gpt = (size_t)b * a.n_per_image + nn;
+        const size_t act_layer = (size_t)a.act_points * H;
+
+        // ---- head backward -------------------------------------------------------------------------------------------
+        f32x4 go = *reinterpret_cast<const f32x4*>(a.grad_out + gpt * 4);
+        if (!valid) go = f32x4{0.f, 0.f, 0.f, 0.f};        // padded lanes shadow the last point: they must add nothing
+        if (a.flags & CNERF_F_SIGMOID_RGB) {
+            const f32x4 so = *reinterpret_cast<const f32x4*>(a.saved_out + gpt * 4);
+            go[0] = go[0] * (so[0] * (1.0f - so[0]));
+            go[1] = go[1] * (so[1] * (1.0f - so[1]));
+            go[2] = go[2] * (so[2] * (1.0f - so[2]));
+        }
+        if (valid && h == 0) *reinterpret_cast<f32x4*>(a.act_go + gpt * 4) = go;
+
+        Act<NT> g, g2;
+        // packed_t layout: [head^T: NT tiles x 2 k-steps x 64 lanes floats, padded to float4 groups][layers L..1 transposed]
+        const float* wt = a.packed_t;
+        {
+            const float b0 = h ? go[1] : go[0], b1 = h ? go[3] : go[2];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wt[(t * 2 + 0) * 64 + lane], b0, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wt[(t * 2 + 1) * 64 + lane], b1, acc, 0, 0, 0);
+                g.v[t] = acc;
+            }
+            wt += (size_t)NT * 2 * 64;
+        }
+        const f32x4* wp = reinterpret_cast<const f32x4*>(wt);
+        const float* ones = a.bias + a.bias_floats;
+        int film_idx = 0;
+        for (int l = 0; l < a.L; ++l) film_idx += (a.layer_kind[l] == CNERF_LAYER_FILM);
+        for (int l = a.L - 1; l >= 0; --l) {
+            const bool film = a.layer_kind[l] == CNERF_LAYER_FILM;
+            if (film) --film_idx;
+            const float* fr = film ? a.freq + (size_t)b * a.film_stride + (size_t)film_idx * H : ones;
+            bwd_activation<NT>(g.v, a.act_c + (size_t)l * act_layer + gpt * H, a.act_g + (size_t)l * act_layer + gpt * H, fr, h);
+            if (l > 0) {
+                bwd_matrix<NT, NT>(wp, g.v, g2.v, lane);
+                wp += (size_t)NT * NT * TILE4;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) g.v[t] = g2.v[t];
+            }
+        }
+        // ---- first layer: 32 feature channels ----------------------------------------------------------------------------
+        f32x16 gfeat;
+        bwd_matrix<1, NT>(wp, g.v, &gfeat, lane);
+
+        // ---- trilinear scatter-add ----------------------------------------------------------------------------------------
+        float px, py, pz;
+        tile_point(a, b, nn, valid, h, false, px, py, pz);
+        Corner8 cr;
+        trilinear_corners(px, py, pz, a.half_voxel, a.V, cr);
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s_g[wv][j][8 * gq + 4 * h + e] = gfeat[4 * gq + e];
+        if (h == 0) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                s_base[wv][j][k] = cr.base[k];
+                s_w[wv][j][k] = valid ? cr.w[k] : 0.0f;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        float* gv = a.grad_fvol + (size_t)b * a.V * a.V * a.V * 32;
+        const int ch = lane & 31;
+        for (int pp = 0; pp < 16; ++pp) {
+            const int p = 2 * pp + h;                      // two points per wave instruction, 32 channels each
+            const float gval = s_g[wv][p][ch];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float wk = s_w[wv][p][k];
+                if (wk != 0.0f) atomicAdd(gv + (size_t)s_base[wv][p][k] * 32 + ch, gval * wk);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // host-side launchers (called from cnerf_abi.hip)
 // ---------------------------------------------------------------------------------------------------------------
+// Transposed pack: the matrix M = W^T (rows = inputs of the layer, cols = outputs) in the same A-operand order:
+//   value[e] = M[32t + (lane&31)][32tk + 8g + 4(lane>>5) + e] = W[32tk + 8g + 4(lane>>5) + e][32t + (lane&31)]
+// w is (n_rows_w, n_cols_w) row-major; OT = n_cols_w / 32 output tiles, KT = n_rows_w / 32.
+__global__ void pack_matrix_t_kernel(const float* __restrict__ w, int n_rows_w, int n_cols_w, int OT, float* __restrict__ dst) {
+    const int KT = n_rows_w / 32;
+    const int total = OT * KT * 4 * 64 * 4;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int e = idx & 3;
+        const int lane = (idx >> 2) & 63;
+        const int g = (idx >> 8) & 3;
+        const int rest = idx >> 10;
+        const int tk = rest % KT, t = rest / KT;
+        const int mrow = 32 * t + (lane & 31);                       // column of W
+        const int mcol = 32 * tk + 8 * g + 4 * (lane >> 5) + e;      // row of W
+        dst[idx] = w[(size_t)mcol * n_cols_w + mrow];
+    }
+}
+
+// head^T for the backward: float index (t*2 + s)*64 + lane = W_head[2s + (lane>>5)][32t + (lane&31)]
+__global__ void pack_head_t_kernel(const float* __restrict__ w, int H, float* __restrict__ dst) {
+    const int total = (H / 32) * 2 * 64;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < total) {
+        const int lane = idx & 63, s = (idx >> 6) & 1, t = idx >> 7;
+        dst[idx] = w[(size_t)(2 * s + (lane >> 5)) * H + 32 * t + (lane & 31)];
+    }
+}
+
+hipError_t launch_pack_matrix_t(const float* w, int n_rows_w, int n_cols_w, int OT, float* dst, hipStream_t stream) {
+    const int total = OT * (n_rows_w / 32) * 4 * 64 * 4;
+    hipLaunchKernelGGL(pack_matrix_t_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, w, n_rows_w, n_cols_w, OT, dst);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_head_t(const float* w, int H, float* dst, hipStream_t stream) {
+    const int total = (H / 32) * 2 * 64;
+    hipLaunchKernelGGL(pack_head_t_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, w, H, dst);
+    return hipGetLastError();
+}
+
 __global__ void fill_kernel(float* dst, float value, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = value;
@@ -355,19 +625,42 @@ hipError_t launch_pack_matrix(const float* w, int n_out, int K, int OT, float* d
     return hipGetLastError();
 }
 
-template <int NT, bool HAS_RES>
-static hipError_t launch_field_nt(const FieldArgs& a, hipStream_t stream) {
+static int field_grid(const void* kernel, long long total_tiles) {
     int dev = 0, cus = 256, per_cu = 1;
     if (hipGetDevice(&dev) != hipSuccess) dev = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, field_tile_kernel<NT, HAS_RES>, 256, 0) != hipSuccess || per_cu < 1)
-        per_cu = 1;
-    long long want = (a.total_tiles + 3) / 4;
-    long long cap = (long long)cus * per_cu;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    const long long want = (total_tiles + 3) / 4, cap = (long long)cus * per_cu;
     int blocks = (int)(want < cap ? want : cap);
     if (blocks < 8) blocks = 8;               // every XCD class owns an eighth of the tiles
-    blocks = (blocks + 7) / 8 * 8;
-    hipLaunchKernelGGL((field_tile_kernel<NT, HAS_RES>), dim3(blocks), dim3(256), 0, stream, a);
+    return (blocks + 7) / 8 * 8;
+}
+
+template <int NT>
+static hipError_t launch_field_backward_nt(const FieldArgs& a, hipStream_t stream) {
+    const int blocks = field_grid((const void*)field_backward_kernel<NT>, a.total_tiles);
+    hipLaunchKernelGGL(field_backward_kernel<NT>, dim3(blocks), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_field_backward(const FieldArgs& a, int H, hipStream_t stream) {
+    switch (H / 32) {
+        case 2: return launch_field_backward_nt<2>(a, stream);
+        case 4: return launch_field_backward_nt<4>(a, stream);
+        case 8: return launch_field_backward_nt<8>(a, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+template <int NT, bool HAS_RES>
+static hipError_t launch_field_nt(const FieldArgs& a, hipStream_t stream) {
+    if (a.act_h) {   // activation-storing forward of the backward pass (no residual blocks)
+        const int blocks = field_grid((const void*)field_tile_kernel<NT, false, true>, a.total_tiles);
+        hipLaunchKernelGGL((field_tile_kernel<NT, false, true>), dim3(blocks), dim3(256), 0, stream, a);
+    } else {
+        const int blocks = field_grid((const void*)field_tile_kernel<NT, HAS_RES, false>, a.total_tiles);
+        hipLaunchKernelGGL((field_tile_kernel<NT, HAS_RES, false>), dim3(blocks), dim3(256), 0, stream, a);
+    }
     return hipGetLastError();
 }
 

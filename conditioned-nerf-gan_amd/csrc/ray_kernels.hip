@@ -286,6 +286,183 @@ __global__ __launch_bounds__(256) void merge_composite_kernel(MergeArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Backward of merge + final composite + epilogue: d(loss)/d(pixels, depth) -> d(loss)/d(rgb_sigma) of the coarse and
+// fine samples.  One wave per ray; the forward quantities (alpha, transmittance, weights) are recomputed from the saved
+// rgb_sigma / z, the dependence of T_i on earlier alphas is a reverse (suffix) scan.
+//   w_i = alpha_i T_i, T_i = prod_{j<i} s_j, s_j = 1 - alpha_j + 1e-10
+//   dL/dalpha_i = Gw_i T_i - (sum_{k>i} Gw_k w_k) / s_i ,   dL/dsigma_i = dL/dalpha_i * delta_i exp(-delta_i dens_i) act'(.)
+// Autograd twin of fancy_integration (volumetric_rendering.py:18-70) and generators.py:162-186.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void merge_composite_backward_kernel(MergeBwdArgs a) {
+    __shared__ float s_z[RAYS_PER_BLOCK][MAX_N];
+    __shared__ f32x4 s_rs[RAYS_PER_BLOCK][MAX_N];
+    __shared__ float s_zs[RAYS_PER_BLOCK][MAX_N];
+    __shared__ f32x4 s_rss[RAYS_PER_BLOCK][MAX_N];
+    __shared__ int s_src[RAYS_PER_BLOCK][MAX_N];
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    const long long ray_raw = (long long)blockIdx.x * RAYS_PER_BLOCK + wv;
+    const bool live = ray_raw < a.rays;
+    const long long ray = live ? ray_raw : a.rays - 1;
+    const int S = a.S;
+    const bool hier = a.fine_z != nullptr;
+    const int n = hier ? 2 * S : S;
+
+    const f32x4* crs = reinterpret_cast<const f32x4*>(a.coarse_rgb_sigma) + ray * S;
+    const float* cz = a.coarse_z + ray * S;
+    if (hier) {
+        const f32x4* frs = reinterpret_cast<const f32x4*>(a.fine_rgb_sigma) + ray * S;
+        const float* fz = a.fine_z + ray * S;
+#pragma unroll
+        for (int c = 0; c < CHUNKS; ++c) {
+            const int i = c * WAVE + lane;
+            if (i < n) {
+                s_z[wv][i] = (i < S) ? fz[i] : cz[i - S];
+                s_rs[wv][i] = (i < S) ? frs[i] : crs[i - S];
+            }
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int c = 0; c < CHUNKS; ++c) {
+            const int i = c * WAVE + lane;
+            if (i < n) {
+                const float zi = s_z[wv][i];
+                int rank = 0;
+                for (int j = 0; j < n; ++j) {
+                    const float zj = s_z[wv][j];
+                    rank += (zj < zi) || (zj == zi && j < i);
+                }
+                s_zs[wv][rank] = zi;
+                s_rss[wv][rank] = s_rs[wv][i];
+                s_src[wv][rank] = i;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < CHUNKS; ++c) {
+            const int i = c * WAVE + lane;
+            if (i < n) {
+                s_zs[wv][i] = cz[i];
+                s_rss[wv][i] = crs[i];
+                s_src[wv][i] = i + S;    // "coarse" slot of the cat[fine, coarse] index space
+            }
+        }
+    }
+    wave_lds_sync();
+
+    // upstream gradients of this ray
+    const int R = a.geom.R;
+    const long long P = (long long)R * R;
+    const long long b = ray / P, p = ray - b * P;
+    const int row = (int)(p / R), col = (int)(p - (long long)row * R);
+    float dx, dy, dz;
+    camera_dir(a.geom, row, col, dx, dy, dz);
+    const float* gp = a.grad_pixels + b * 3 * P + p;
+    const float gr = 2.0f * gp[0], gg = 2.0f * gp[P], gb = 2.0f * gp[2 * P];   // pixels = 2 rgb - 1
+    const float gd = a.grad_depth ? dz * a.grad_depth[ray] : 0.0f;              // depth = dir_z * dist
+    const float* eps = a.eps ? a.eps + ray * n : nullptr;
+
+    // forward recompute (same arithmetic as composite_ray) keeping alpha, trans, exp(-delta dens), act'
+    float alpha[CHUNKS], trans[CHUNKS], w[CHUNKS], dsig[CHUNKS], sft[CHUNKS];
+    f32x4 cv[CHUNKS];
+    float zv[CHUNKS];
+    double carry = 1.0, wsum_d = 0.0;
+#pragma unroll
+    for (int c = 0; c < CHUNKS; ++c) {
+        const int i = c * WAVE + lane;
+        const bool act = i < n;
+        alpha[c] = 0.f; trans[c] = 0.f; w[c] = 0.f; dsig[c] = 0.f; sft[c] = 1.0f;
+        cv[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        zv[c] = 0.f;
+        if (c * WAVE < n) {
+            if (act) {
+                const f32x4 v = s_rss[wv][i];
+                const float zi = s_zs[wv][i];
+                const float delta = (i == n - 1) ? 1e10f : (s_zs[wv][i + 1] - zi);
+                const float noisy = v[3] + (eps ? eps[i] * a.noise_std : 0.0f);
+                float dens, dact;
+                if (a.flags & CNERF_F_SOFTPLUS) {
+                    dens = softplus20(noisy);
+                    dact = noisy > 20.0f ? 1.0f : sigmoidf_(noisy);
+                } else {
+                    dens = fmaxf(noisy, 0.0f);
+                    dact = noisy > 0.0f ? 1.0f : 0.0f;
+                }
+                const float ex = expf(-delta * dens);
+                alpha[c] = 1.0f - ex;
+                sft[c] = 1.0f - alpha[c] + 1e-10f;
+                dsig[c] = delta * ex * dact;        // d alpha / d sigma
+                cv[c] = v;
+                zv[c] = zi;
+            }
+            const double incl = wave_incl_prod((double)sft[c], lane);
+            double excl = __shfl_up(incl, 1, WAVE);
+            if (lane == 0) excl = 1.0;
+            trans[c] = (float)(carry * excl);
+            w[c] = act ? alpha[c] * trans[c] : 0.0f;
+            carry *= __shfl(incl, WAVE - 1, WAVE);
+            wsum_d += wave_sum((double)w[c]);
+        }
+    }
+    const float wsum = (float)wsum_d;
+    // dL/dw' (w' = weights after last_back), then dL/dw
+    float G[CHUNKS];
+    float g_last = 0.0f;
+#pragma unroll
+    for (int c = 0; c < CHUNKS; ++c) {
+        G[c] = gr * cv[c][0] + gg * cv[c][1] + gb * cv[c][2] + gd * zv[c];
+        if (c * WAVE <= n - 1 && n - 1 < (c + 1) * WAVE) g_last = __shfl(G[c], (n - 1) - c * WAVE, WAVE);
+    }
+    const float white = (a.flags & CNERF_F_WHITE_BACK) ? (gr + gg + gb) : 0.0f;
+    float wl[CHUNKS];   // weights as used in rgb = sum w' c (needed for dL/dc)
+#pragma unroll
+    for (int c = 0; c < CHUNKS; ++c) {
+        const int i = c * WAVE + lane;
+        wl[c] = w[c];
+        if (a.flags & CNERF_F_LAST_BACK) {
+            if (i == n - 1) {
+                wl[c] = w[c] + (1.0f - wsum);
+                G[c] = 0.0f;                 // w'_{n-1} = 1 - sum_{j<n-1} w_j does not depend on w_{n-1}
+            } else {
+                G[c] = G[c] - g_last;
+            }
+        }
+        G[c] = (i < n) ? G[c] - white : 0.0f;
+    }
+    // suffix sums of G_k w_k  (k > i), in double, chunk by chunk from the far end
+    double tail = 0.0;
+    float gsig[CHUNKS];
+#pragma unroll
+    for (int c = CHUNKS - 1; c >= 0; --c) {
+        gsig[c] = 0.0f;
+        if (c * WAVE < n) {
+            const double v = (double)G[c] * (double)w[c];
+            // inclusive suffix within the chunk = total - inclusive prefix + own
+            const double pre = wave_incl_sum(v, lane);
+            const double tot = __shfl(pre, WAVE - 1, WAVE);
+            const double suf_excl = (tot - pre) + tail;          // sum over k > i inside chunk + later chunks
+            const float dalpha = G[c] * trans[c] - (float)(suf_excl / (double)sft[c]);
+            gsig[c] = dalpha * dsig[c];
+            tail += tot;
+        }
+    }
+    if (!live) return;
+    // scatter back to the unsorted coarse / fine arrays
+    float* gc = a.grad_coarse + ray * S * 4;
+    float* gf = hier ? a.grad_fine + ray * S * 4 : nullptr;
+#pragma unroll
+    for (int c = 0; c < CHUNKS; ++c) {
+        const int i = c * WAVE + lane;
+        if (i < n) {
+            const int src = s_src[wv][i];
+            f32x4 o = {gr * wl[c], gg * wl[c], gb * wl[c], gsig[c]};
+            float* dst = (src < S) ? gf + src * 4 : gc + (src - S) * 4;
+            *reinterpret_cast<f32x4*>(dst) = o;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // (B,C,V^3) <-> (B,V^3,C), C == 32: tiles of 32 channels x 64 voxels through LDS
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void transpose_cl_kernel(const float* __restrict__ src, float* __restrict__ dst,
@@ -358,6 +535,11 @@ hipError_t launch_resample(const ResampleArgs& a, hipStream_t stream) {
 hipError_t launch_merge_composite(const MergeArgs& a, hipStream_t stream) {
     const unsigned blocks = (unsigned)((a.rays + RAYS_PER_BLOCK - 1) / RAYS_PER_BLOCK);
     hipLaunchKernelGGL(merge_composite_kernel, dim3(blocks), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+hipError_t launch_merge_composite_backward(const MergeBwdArgs& a, hipStream_t stream) {
+    const unsigned blocks = (unsigned)((a.rays + RAYS_PER_BLOCK - 1) / RAYS_PER_BLOCK);
+    hipLaunchKernelGGL(merge_composite_backward_kernel, dim3(blocks), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 hipError_t launch_transpose_cl(int B, int C, int V, const float* src, float* dst, bool to_channel_last,

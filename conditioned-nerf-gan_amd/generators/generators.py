@@ -59,7 +59,7 @@ class ImplicitGenerator3d(nn.Module):
                 if noise_std != 0:
                     rng["eps_final"] = eps_f
         aux_out = kwargs.get("_aux")
-        pixels, depth, aux = ops.render_forward(net, fvol, freq, phase, cam2worlds, R, fov, ray_start, ray_end, S,
+        pixels, depth, aux = ops.render(net, fvol, freq, phase, cam2worlds, R, fov, ray_start, ray_end, S,
                                         bool(hierarchical_sample), clamp_mode, noise_std, white_back, last_back, rng,
                                         want_aux=aux_out is not None, field_events=kwargs.get("_field_events"))
         if aux_out is not None:

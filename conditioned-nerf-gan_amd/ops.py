@@ -168,7 +168,7 @@ HIER_ONLY = {"coarse_weights", "cdf", "inds", "fine_z", "fine_rgb_sigma", "sort_
 
 def render_forward(net, fvol, freq, phase, cam2world, img_size, fov, ray_start, ray_end, num_steps, hierarchical,
                    clamp_mode, noise_std, white_back=False, last_back=False, rng: Optional[dict] = None,
-                   want_aux=False, fvol_is_channel_last=False, field_events=None):
+                   want_aux=False, fvol_is_channel_last=False, field_events=None, aux_keys=None):
     """ImplicitGenerator3d.forward on the GPU.  rng: dict with u_strat / eps_coarse / u_fine / eps_final tensors.
     field_events: optional 4 hipEvent_t handles (ints) recorded around the two field-kernel launches."""
     cam2world = _f32(cam2world)
@@ -191,9 +191,9 @@ def render_forward(net, fvol, freq, phase, cam2world, img_size, fov, ray_start, 
     for t in keep:
         L.ptr(t)   # validates device / contiguity
     aux_t, aux_s = {}, None
-    if want_aux:
+    if want_aux or aux_keys:
         aux_s = L.Aux()
-        for k in L.AUX_FIELDS:
+        for k in (L.AUX_FIELDS if want_aux else aux_keys):
             if not hierarchical and k in HIER_ONLY:
                 continue
             shape, dt = AUX_SHAPES[k](B, P, S, n)
@@ -208,3 +208,169 @@ def render_forward(net, fvol, freq, phase, cam2world, img_size, fov, ray_start, 
                                          C.byref(aux_s) if aux_s is not None else None, L.ptr(ws), _stream()),
             "cnerf_render_forward")
     return pixels, depth, aux_t
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# autograd
+# ---------------------------------------------------------------------------------------------------------------------
+_packt_cache: Dict[int, tuple] = {}
+SAVED_KEYS = ("coarse_rgb_sigma", "coarse_z", "fine_rgb_sigma", "fine_z")
+
+
+def pack_field_transposed(net, cfg):
+    params = [_f32(p.detach()) for p in net.field_params()]
+    key = tuple((p.data_ptr(), p._version) for p in net.field_params())
+    hit = _packt_cache.get(id(net))
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    nb = C.c_size_t(0)
+    L.check(L.lib().cnerf_backward_bytes(C.byref(cfg), C.byref(nb)), "cnerf_backward_bytes")
+    packed_t = torch.empty(nb.value // 4, dtype=torch.float32, device=params[0].device)
+    fp = L.FieldParams()
+    it = iter(params)
+    for i, kind in enumerate(net.spec.layers):
+        fp.w[i], fp.b[i] = next(it).data_ptr(), next(it).data_ptr()
+        if kind == "res":
+            fp.w2[i], fp.b2[i] = next(it).data_ptr(), next(it).data_ptr()
+    fp.w_final, fp.b_final = next(it).data_ptr(), next(it).data_ptr()
+    L.check(L.lib().cnerf_pack_field_transposed(C.byref(cfg), C.byref(fp), L.ptr(packed_t), _stream()),
+            "cnerf_pack_field_transposed")
+    packed_t._keepalive = params
+    _packt_cache[id(net)] = (key, packed_t)
+    return packed_t
+
+
+ACT_BUDGET_BYTES = 48 << 30     # activation / gradient chunk buffers of the backward (288 GB HBM per GPU)
+
+
+def render_backward(net, o, fvol_cl, freq, phase, cam2world, rng, saved, grad_pixels, grad_depth):
+    """Gradients of one render w.r.t. (feature volume (B,C,V,V,V), freq, phase, [field parameters])."""
+    B, R, S, hier = o["B"], o["R"], o["S"], o["hier"]
+    dev = cam2world.device
+    cfg = make_cfg(net, B, fvol_cl.shape[1], R, S, o["fov"], o["ray_start"], o["ray_end"], o["noise_std"], hier,
+                   o["white_back"], o["last_back"], o["clamp_mode"])
+    packed = pack_field(net, cfg)
+    packed_t = pack_field_transposed(net, cfg)
+    H, Cin = int(net.hidden_dim), int(net.input_dim)
+    kinds = net.spec.layers
+    nl = len(kinds)
+    npi = R * R * S
+    c_rs, c_z, f_rs, f_z = saved
+    gc = torch.empty_like(c_rs)
+    gf = torch.empty_like(f_rs) if hier else None
+    grad_pixels = _f32(grad_pixels)
+    grad_depth = _f32(grad_depth) if grad_depth is not None else None
+    eps_final = _f32(rng.get("eps_final")) if o["noise_std"] != 0 else None
+    L.check(L.lib().cnerf_merge_composite_backward(C.byref(cfg), L.ptr(c_rs), L.ptr(c_z), L.ptr(f_rs) if hier else None,
+                                                   L.ptr(f_z) if hier else None, L.ptr(eps_final), L.ptr(grad_pixels),
+                                                   L.ptr(grad_depth), L.ptr(gc), L.ptr(gf) if hier else None, _stream()),
+            "cnerf_merge_composite_backward")
+
+    params = net.field_params()
+    Ws, bs = [], []
+    it = iter(params)
+    for _ in kinds:
+        Ws.append(next(it).detach()); bs.append(next(it).detach())
+    W_head = next(it).detach()
+    dW = [torch.zeros_like(w) for w in Ws]
+    db = [torch.zeros_like(b) for b in bs]
+    dW_head = torch.zeros_like(W_head)
+    db_head = torch.zeros(4, dtype=torch.float32, device=dev)
+    n_film = sum(1 for k in kinds if k == "film")
+    g_freq = torch.zeros((B, n_film * H), dtype=torch.float32, device=dev) if n_film else None
+    g_phase = torch.zeros_like(g_freq) if n_film else None
+    grad_fvol_cl = torch.zeros_like(fvol_cl)
+
+    per_image = npi * (32 + 3 * nl * H + 4) * 4
+    nb = max(1, min(B, ACT_BUDGET_BYTES // per_image))
+    act = None
+    u_strat, fine_z_used = _f32(rng.get("u_strat")), f_z
+    passes = [(0, gc, c_rs)] + ([(1, gf, f_rs)] if hier else [])
+    for pss, g_out, saved_out in passes:
+        for b0 in range(0, B, nb):
+            cnt = min(nb, B - b0)
+            n = cnt * npi
+            if act is None or act[0].shape[0] != n:
+                act = (torch.empty((n, 32), dtype=torch.float32, device=dev),
+                       torch.empty((nl, n, H), dtype=torch.float32, device=dev),
+                       torch.empty((nl, n, H), dtype=torch.float32, device=dev),
+                       torch.empty((nl, n, H), dtype=torch.float32, device=dev),
+                       torch.empty((n, 4), dtype=torch.float32, device=dev))
+            a_feat, a_h, a_c, a_g, a_go = act
+            L.check(L.lib().cnerf_field_backward(C.byref(cfg), pss, b0, cnt, L.ptr(fvol_cl), L.ptr(packed), L.ptr(packed_t),
+                                                 L.ptr(freq), L.ptr(phase), L.ptr(cam2world), L.ptr(u_strat),
+                                                 L.ptr(fine_z_used) if hier else None, L.ptr(g_out), L.ptr(saved_out),
+                                                 L.ptr(a_feat), L.ptr(a_h), L.ptr(a_c), L.ptr(a_g), L.ptr(a_go),
+                                                 L.ptr(grad_fvol_cl), _stream()), "cnerf_field_backward")
+            # parameter gradients: plain GEMMs and column sums over the chunk matrices (rocBLAS through torch)
+            fidx = 0
+            for l, kind in enumerate(kinds):
+                X = (a_feat if l == 0 else a_h[l - 1]).view(cnt, npi, -1)
+                G = a_g[l].view(cnt, npi, H)
+                dWarg = torch.bmm(G.transpose(1, 2), X)          # (cnt, H, K) per image
+                cs = G.sum(1)                                    # (cnt, H)
+                if kind == "film":
+                    sl = slice(fidx * H, (fidx + 1) * H)
+                    f = freq[b0:b0 + cnt, sl]
+                    dW[l] += (f.unsqueeze(-1) * dWarg).sum(0)
+                    db[l] += (f * cs).sum(0)
+                    g_phase[b0:b0 + cnt, sl] += cs
+                    g_freq[b0:b0 + cnt, sl] += (Ws[l].unsqueeze(0) * dWarg).sum(-1) + bs[l].unsqueeze(0) * cs
+                    fidx += 1
+                else:
+                    dW[l] += dWarg.sum(0)
+                    db[l] += cs.sum(0)
+            dW_head += a_go.t() @ a_h[nl - 1]
+            db_head += a_go.sum(0)
+    grads = []
+    for l in range(nl):
+        grads += [dW[l], db[l]]
+    grads += [dW_head, db_head]
+    return grad_fvol_cl, g_freq, g_phase, grads
+
+
+class RenderFunction(torch.autograd.Function):
+    """ImplicitGenerator3d.forward as one autograd node: differentiable w.r.t. the feature volume, freq/phase (and through
+    them the mapping network and the global feature) and the field parameters; not w.r.t. cameras or sample positions
+    (the reference runs those under no_grad: generators.py:57,111)."""
+
+    @staticmethod
+    def forward(ctx, net, o, rng, fvol, freq, phase, cam2world, *params):
+        fvol_cl = channel_last(fvol.detach())
+        fr = freq.detach() if freq is not None else None
+        ph = phase.detach() if phase is not None else None
+        need_grad = any(ctx.needs_input_grad)   # (grad mode is always off inside Function.forward)
+        pixels, depth, aux = render_forward(net, fvol_cl, fr, ph, cam2world, o["R"], o["fov"], o["ray_start"], o["ray_end"],
+                                            o["S"], o["hier"], o["clamp_mode"], o["noise_std"], o["white_back"],
+                                            o["last_back"], rng, want_aux=o["want_aux"], fvol_is_channel_last=True,
+                                            field_events=o.get("field_events"),
+                                            aux_keys=SAVED_KEYS if need_grad and not o["want_aux"] else None)
+        ctx.net, ctx.o, ctx.rng = net, o, rng
+        ctx.aux = aux
+        if need_grad:
+            saved = [aux.get(k) for k in SAVED_KEYS]
+            if o["hier"] and rng.get("fine_z") is not None:
+                saved[3] = _f32(rng["fine_z"]).reshape(saved[1].shape)   # teacher-forced depths are what the fine pass used
+            ctx.saved = (fvol_cl, fr, ph, _f32(cam2world), tuple(saved))
+        RenderFunction.last_aux = aux
+        return pixels, depth
+
+    @staticmethod
+    def backward(ctx, grad_pixels, grad_depth):
+        fvol_cl, fr, ph, cam2world, saved = ctx.saved
+        g_fvol_cl, g_freq, g_phase, g_params = render_backward(ctx.net, ctx.o, fvol_cl, fr, ph, cam2world, ctx.rng, saved,
+                                                               grad_pixels.contiguous(),
+                                                               grad_depth.contiguous() if grad_depth is not None else None)
+        return (None, None, None, channel_first(g_fvol_cl), g_freq, g_phase, None, *g_params)
+
+
+def render(net, fvol, freq, phase, cam2world, img_size, fov, ray_start, ray_end, num_steps, hierarchical, clamp_mode,
+           noise_std, white_back=False, last_back=False, rng=None, want_aux=False, field_events=None):
+    """Differentiable entry used by ImplicitGenerator3d.forward.  Returns (pixels, depth, aux dict)."""
+    o = dict(B=cam2world.shape[0], R=int(img_size), S=int(num_steps), fov=float(fov), ray_start=float(ray_start),
+             ray_end=float(ray_end), hier=bool(hierarchical), clamp_mode=clamp_mode, noise_std=float(noise_std),
+             white_back=bool(white_back), last_back=bool(last_back), want_aux=bool(want_aux), field_events=field_events)
+    if clamp_mode not in ("relu", "softplus"):
+        raise TypeError("Need to choose clamp mode")
+    pixels, depth = RenderFunction.apply(net, o, rng or {}, fvol, freq, phase, cam2world, *net.field_params())
+    return pixels, depth, (RenderFunction.last_aux if want_aux else {})

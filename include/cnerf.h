@@ -160,6 +160,44 @@ int cnerf_render_forward(const cnerf_cfg* cfg, const float* fvol_cl, const float
                          const float* phase, const float* cam2world, const cnerf_rng* rng, float* pixels,
                          float* depth, const cnerf_aux* aux, void* workspace, void* stream);
 
+/* ---- backward (autograd twin of cnerf_render_forward; gradients flow to the field parameters, freq/phase and the
+ * feature volume, never to cam2world or the sample positions: generators.py:57,111 run them under no_grad) ----------
+ *
+ * Step 1  cnerf_merge_composite_backward: d(pixels, depth) -> d(rgb_sigma) of the coarse and the fine samples.
+ * Step 2  cnerf_field_backward per pass (coarse, fine) and per chunk of images: re-runs the field forward storing the
+ *         activations, back-propagates through the MLP on the MFMA units, scatter-adds d(feature volume) with fp32
+ *         atomics, and leaves row-major activation / gradient matrices in the caller's chunk buffers:
+ *             act_feat (n,32)   x0 = looked-up features            act_go (n,4)   d/d head pre-activation
+ *             act_h (L,n,H)     x_l = sin(arg_l)                    act_g  (L,n,H) d/d arg_l
+ *             act_c (L,n,H)     cos(arg_l)                          (n = images_in_chunk * points_per_image)
+ *         The parameter gradients are then plain GEMMs / column sums over these matrices (rocBLAS territory):
+ *             dWarg_l = act_g[l]^T x_{l-1};  dW_l = diag(freq_l) dWarg_l;  db_l = freq_l * colsum(act_g[l])
+ *             dphase_l = colsum(act_g[l]);   dfreq_l = rowsum(W_l * dWarg_l) + b_l * dphase_l   (per image)
+ *             dW_head = act_go^T x_L;        db_head = colsum(act_go)
+ * Residual (CNERF_LAYER_RES) networks are not supported by the backward yet: CNERF_ENOSYS. */
+
+/* packed_t: transposed packed weights for the backward; bytes via cnerf_backward_bytes. */
+int cnerf_backward_bytes(const cnerf_cfg* cfg, size_t* packed_t);
+int cnerf_pack_field_transposed(const cnerf_cfg* cfg, const cnerf_field_params* params, float* packed_t, void* stream);
+
+/* saved tensors are the forward's coarse/fine rgb_sigma and z (cnerf_aux); fine_* may be NULL when not hierarchical.
+ * grad_depth may be NULL.  Outputs grad_coarse / grad_fine: (B,P,S,4). */
+int cnerf_merge_composite_backward(const cnerf_cfg* cfg, const float* coarse_rgb_sigma, const float* coarse_z,
+                                   const float* fine_rgb_sigma, const float* fine_z, const float* eps_final,
+                                   const float* grad_pixels, const float* grad_depth, float* grad_coarse,
+                                   float* grad_fine, void* stream);
+
+/* pass: 0 = coarse samples (needs u_strat as in the forward), 1 = fine samples (needs fine_z), 2 = explicit points:
+ * the u_strat argument then carries points (B, R*R*S, 3) (backward of cnerf_field_forward).  Images [image0,
+ * image0 + n_images) of the call described by cfg.  All per-image inputs are the FULL tensors of the forward (the
+ * function offsets them); grad_rgb_sigma / saved_rgb_sigma are the (B,P,S,4) tensors of that pass; grad_fvol_cl is the
+ * full (B,V,V,V,32) gradient volume, accumulated into (zero it first).  act_* are chunk buffers for n_images images. */
+int cnerf_field_backward(const cnerf_cfg* cfg, int32_t pass, int32_t image0, int32_t n_images, const float* fvol_cl,
+                         const float* packed, const float* packed_t, const float* freq, const float* phase,
+                         const float* cam2world, const float* u_strat, const float* fine_z,
+                         const float* grad_rgb_sigma, const float* saved_rgb_sigma, float* act_feat, float* act_h,
+                         float* act_c, float* act_g, float* act_go, float* grad_fvol_cl, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

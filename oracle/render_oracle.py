@@ -281,20 +281,28 @@ def render(variant: str, params: Dict[str, torch.Tensor], fvol_cf: torch.Tensor,
            ray_start: float, ray_end: float, S: int, hierarchical: bool, clamp_mode: str,
            noise_std: float, white_back: bool, last_back: bool, u_strat: torch.Tensor,
            eps_coarse: Optional[torch.Tensor] = None, u_fine: Optional[torch.Tensor] = None,
-           eps_final: Optional[torch.Tensor] = None, explicit_lookup: bool = False) -> RenderOut:
+           eps_final: Optional[torch.Tensor] = None, explicit_lookup: bool = False,
+           forced_fine_z: Optional[torch.Tensor] = None) -> RenderOut:
+    """forced_fine_z (B,P,S): test hook, replaces the resampled depths downstream of the resampling (teacher forcing,
+    the twin of cnerf_rng.fine_z); inds / cdf / the resampled depths are still returned in aux."""
     spec = FIELD_SPECS[variant]
     B, P = cam2world.shape[0], R * R
     aux: Dict[str, torch.Tensor] = {}
-    dirs_cam = camera_ray_dirs(R, fov)
-    z_lin, offset, z = stratified_depths(B, R, S, ray_start, ray_end, u_strat)
-    pts, dirs_w, origins = coarse_world_points(cam2world, dirs_cam, z_lin, offset)
+    with torch.no_grad():                                   # generators.py:57-93: rays and samples carry no gradient
+        dirs_cam = camera_ray_dirs(R, fov)
+        z_lin, offset, z = stratified_depths(B, R, S, ray_start, ray_end, u_strat)
+        pts, dirs_w, origins = coarse_world_points(cam2world, dirs_cam, z_lin, offset)
     c_out, c_feat = field_eval(spec, params, fvol_cf, global_feature, pts.reshape(B, P * S, 3), explicit_lookup)
     c_out = c_out.reshape(B, P, S, 4)
     aux.update(coarse_points=pts, coarse_z=z, coarse_feat=c_feat, coarse_rgb_sigma=c_out)
     if hierarchical:
-        _, _, w = composite(c_out, z, eps_coarse, noise_std, clamp_mode)
-        fine_z, inds, cdf = importance_depths(z, w, u_fine)
-        fpts = origins.reshape(B, 1, 1, 3) + dirs_w.unsqueeze(2) * fine_z.unsqueeze(-1)
+        with torch.no_grad():                               # generators.py:111-142: resampling is not differentiated
+            _, _, w = composite(c_out, z, eps_coarse, noise_std, clamp_mode)
+            fine_z, inds, cdf = importance_depths(z, w, u_fine)
+            aux["resampled_z"] = fine_z
+            if forced_fine_z is not None:
+                fine_z = forced_fine_z.reshape(B, P, S)
+            fpts = origins.reshape(B, 1, 1, 3) + dirs_w.unsqueeze(2) * fine_z.unsqueeze(-1)
         f_out, _ = field_eval(spec, params, fvol_cf, global_feature, fpts.reshape(B, P * S, 3), explicit_lookup)
         f_out = f_out.reshape(B, P, S, 4)
         all_out, all_z, sort_idx = merge_by_depth(f_out, c_out, fine_z, z)
