@@ -40,6 +40,7 @@ class HipEvents:
         self.hip.hipEventElapsedTime.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, ctypes.c_void_p]
         self.hip.hipEventSynchronize.argtypes = [ctypes.c_void_p]
         self.hip.hipEventDestroy.argtypes = [ctypes.c_void_p]
+        self.hip.hipEventRecord.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
 
     def create(self, n):
         out = []
@@ -56,6 +57,36 @@ class HipEvents:
         return ms.value
 
 
+def timed_region(step, steps, warmup, dist=None, sync=lambda: None, device="cpu"):
+    """W untimed warm-up steps, then exactly K steps bracketed by device sync + barrier on both sides; returns the
+    MAX over ranks of the elapsed seconds.  `dist` is torch.distributed once a process group exists (RCCL on the GPU
+    box, gloo in the CPU test), None for a single process."""
+    for _ in range(warmup):
+        step(None)
+    sync()
+    if dist is not None:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(i)
+    sync()
+    if dist is not None:
+        dist.barrier()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    return elapsed
+
+
+def whole_job_rays_per_s(world, images_per_gpu, img_size, steps, elapsed):
+    """Weak scaling: every rank renders its own images; the job's throughput is all ranks' rays over the slowest rank's time."""
+    return world * images_per_gpu * img_size * img_size * steps / elapsed
+
+
 def synthetic_inputs(B, V, Z, dev, seed):
     """ShapeNetCar-shaped synthetic inputs: unet3d-like feature volume, global feature, cameras."""
     from cnerf_amd.generators.volumetric_rendering import sample_camera_positions, create_cam2world_matrix
@@ -65,6 +96,48 @@ def synthetic_inputs(B, V, Z, dev, seed):
     np.random.seed(seed)
     cam = create_cam2world_matrix(sample_camera_positions("cpu", "y", 0.7, 1.5, B), "y")
     return fvol.to(dev), glob.to(dev), cam.to(dev)
+
+
+def sample_composite_pass(args, gen, fvol, glob, cam, meta, evs):
+    """The unfused sample + composite pass of SURVEY.md 8(d): trilinear lookup that materialises the (N,32) features
+    (cnerf_gather_features) for every coarse and fine sample of one step, plus the compositing of the merged samples
+    (cnerf_composite).  Algorithmic bytes: 1152 B per field evaluation, 20 B per composited sample, 16 B per ray."""
+    import cnerf_amd
+    ops = cnerf_amd.ops
+    B, R, S = args.batch, args.img_size, args.num_steps
+    aux = {}
+    with torch.no_grad():
+        gen((fvol, glob), cam, R, FOV, RAY_START, RAY_END, S, _aux=aux, **meta)
+        fcl = ops.channel_last(fvol)
+        pts = torch.cat([aux["coarse_points"].reshape(B, -1, 3), aux["fine_points"].reshape(B, -1, 3)], 1).contiguous()
+        allz = torch.cat([aux["fine_z"], aux["coarse_z"]], -1)
+        allrs = torch.cat([aux["fine_rgb_sigma"], aux["coarse_rgb_sigma"]], -2)
+        idx = aux["sort_idx"].long()
+        zs = torch.gather(allz, -1, idx).reshape(B * R * R, 2 * S).contiguous()
+        rss = torch.gather(allrs, -2, idx.unsqueeze(-1).expand(-1, -1, -1, 4)).reshape(B * R * R, 2 * S, 4).contiguous()
+        del aux
+        reps = 10
+        ev = evs.create(4)
+        for i in range(reps + 2):
+            if i == 2:
+                evs.hip.hipEventRecord(ev[0], ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+            ops.gather_features(gen.siren, fcl, pts)
+        evs.hip.hipEventRecord(ev[1], ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        for i in range(reps + 2):
+            if i == 2:
+                evs.hip.hipEventRecord(ev[2], ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+            ops.composite(rss, zs, None, 0.0, "relu", True, False)
+        evs.hip.hipEventRecord(ev[3], ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+    t_g = evs.elapsed_ms(ev[0], ev[1]) / reps
+    t_c = evs.elapsed_ms(ev[2], ev[3]) / reps
+    evals, rays = pts.shape[0] * pts.shape[1], B * R * R
+    bytes_g, bytes_c = evals * 1152.0, evals * 20.0 + rays * 16.0
+    gbps = (bytes_g + bytes_c) / ((t_g + t_c) * 1e-3) / 1e9
+    return {"kernels": "gather_kernel (cnerf_gather_features) + composite_kernel (cnerf_composite), unfused",
+            "bound": "hbm", "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS,
+            "traffic": None, "gather_ms": t_g, "composite_ms": t_c, "algorithmic_bytes": bytes_g + bytes_c,
+            "note": "effective bandwidth: neighbouring samples share corner lines in L2 / Infinity Cache (SURVEY.md 8d)"}
 
 
 def cpu_baseline(args, gen_cpu):
@@ -122,6 +195,7 @@ def main():
         args.gpus = world
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -144,6 +218,7 @@ def main():
     B, R, S = args.batch, args.img_size, args.num_steps
     fvol, glob, cam = synthetic_inputs(B, args.volume, args.z_dim, dev, seed=rank)
     meta = dict(clamp_mode="relu", nerf_noise=args.noise, white_back=True, hierarchical_sample=True)
+    meta_nohier = dict(meta)
 
     evs = HipEvents()
     n_ev = 4 * args.steps
@@ -155,24 +230,13 @@ def main():
         with torch.no_grad():
             return gen((fvol, glob), cam, R, FOV, RAY_START, RAY_END, S, _field_events=ev, **meta)
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        out = step(i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
+    last = {}
+
+    def step_i(i):
+        last["out"] = step(i)
+
+    elapsed = timed_region(step_i, args.steps, args.warmup, dist if world > 1 else None, torch.cuda.synchronize, dev)
+    out = last["out"]
     assert torch.isfinite(out[0]).all()
 
     # dominant kernel: field_tile_kernel, two launches per step (coarse, fine), same work each
@@ -189,7 +253,7 @@ def main():
         rays = world * B * R * R * args.steps
         res = {
             "metric": "rays/sec at 128x128x64spp ShapeNetCar",
-            "value": rays / elapsed, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": whole_job_rays_per_s(world, B, R, args.steps, elapsed), "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"ImplicitGenerator3d.forward {args.variant} hidden {args.hidden}, {R}x{R} rays x {S} "
@@ -204,6 +268,8 @@ def main():
                          "flops_per_launch": flops_per_launch,
                          "share_of_step": 2 * avg_ms / (elapsed / args.steps * 1e3)},
         }
+        if world == 1:
+            res["roofline_sample_composite"] = sample_composite_pass(args, gen, fvol, glob, cam, meta, evs)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args, gen_cpu)
         print(json.dumps(res), flush=True)
