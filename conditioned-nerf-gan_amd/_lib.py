@@ -7,7 +7,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libcnerf_hip.so")
 
 MAX_LAYERS = 16
-F_HIERARCHICAL, F_WHITE_BACK, F_LAST_BACK, F_SOFTPLUS, F_SIGMOID_RGB = 1, 2, 4, 8, 16
+MAX_LEVELS = 4
+ABI_VERSION = 2
+F_HIERARCHICAL, F_WHITE_BACK, F_LAST_BACK, F_SOFTPLUS, F_SIGMOID_RGB, F_INPUT_XYZ = 1, 2, 4, 8, 16, 32
 LAYER_FILM, LAYER_SINE, LAYER_RES = 0, 1, 2
 LAYER_CODE = {"film": LAYER_FILM, "sine": LAYER_SINE, "res": LAYER_RES}
 
@@ -16,7 +18,12 @@ class Cfg(C.Structure):
     _fields_ = [("B", C.c_int32), ("R", C.c_int32), ("S", C.c_int32), ("V", C.c_int32), ("C", C.c_int32),
                 ("H", C.c_int32), ("L", C.c_int32), ("layer_kind", C.c_int32 * MAX_LAYERS),
                 ("ray_start", C.c_float), ("ray_end", C.c_float), ("voxel_length", C.c_float),
-                ("noise_std", C.c_float), ("flags", C.c_uint32), ("fov_deg", C.c_double)]
+                ("noise_std", C.c_float), ("flags", C.c_uint32), ("fov_deg", C.c_double),
+                ("n_levels", C.c_int32), ("level_V", C.c_int32 * MAX_LEVELS), ("level_C", C.c_int32 * MAX_LEVELS)]
+
+
+class Volumes(C.Structure):
+    _fields_ = [("level", C.c_void_p * MAX_LEVELS)]
 
 
 class FieldParams(C.Structure):
@@ -46,18 +53,19 @@ PROTOTYPES = {
     "cnerf_fvol_channel_first": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cnerf_pack_field": (C.c_int, [C.POINTER(Cfg), C.POINTER(FieldParams), C.c_void_p, C.c_void_p]),
     "cnerf_gather_features": (C.c_int, [C.POINTER(Cfg), C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
-    "cnerf_field_forward": (C.c_int, [C.POINTER(Cfg), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+    "cnerf_field_forward": (C.c_int, [C.POINTER(Cfg), C.POINTER(Volumes), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_int64, C.c_void_p, C.c_void_p]),
     "cnerf_composite": (C.c_int, [C.POINTER(Cfg), C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_void_p, C.c_void_p]),
     "cnerf_resample": (C.c_int, [C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                  C.c_void_p, C.c_void_p]),
-    "cnerf_render_forward": (C.c_int, [C.POINTER(Cfg), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+    "cnerf_render_forward": (C.c_int, [C.POINTER(Cfg), C.POINTER(Volumes), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.POINTER(Rng), C.c_void_p, C.c_void_p, C.POINTER(Aux), C.c_void_p, C.c_void_p]),
     "cnerf_backward_bytes": (C.c_int, [C.POINTER(Cfg), C.POINTER(C.c_size_t)]),
     "cnerf_pack_field_transposed": (C.c_int, [C.POINTER(Cfg), C.POINTER(FieldParams), C.c_void_p, C.c_void_p]),
     "cnerf_merge_composite_backward": (C.c_int, [C.POINTER(Cfg)] + [C.c_void_p] * 10),
-    "cnerf_field_backward": (C.c_int, [C.POINTER(Cfg), C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 17),
+    "cnerf_field_backward": (C.c_int, [C.POINTER(Cfg), C.c_int32, C.c_int32, C.c_int32, C.POINTER(Volumes)] + [C.c_void_p] * 14 +
+                             [C.POINTER(Volumes), C.c_void_p]),
 }
 
 _lib = None
@@ -78,7 +86,7 @@ def lib():
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(handle, name)
             fn.restype, fn.argtypes = res, args
-        if handle.cnerf_abi_version() != 1:
+        if handle.cnerf_abi_version() != ABI_VERSION:
             raise CnerfError("libcnerf_hip.so ABI version mismatch")
         _lib = handle
     return _lib

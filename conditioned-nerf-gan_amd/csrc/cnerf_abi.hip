@@ -30,7 +30,17 @@ size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 int check_cfg(const cnerf_cfg* c, bool need_render) {
     if (!c) return fail(CNERF_EINVAL, "cfg is NULL");
     if (c->B < 1) return fail(CNERF_EINVAL, "B=%d must be >= 1", c->B);
-    if (c->C != 32) return fail(CNERF_EINVAL, "C=%d: this build supports 32 feature channels", c->C);
+    if (c->C < 32 || c->C % 32 != 0 || c->C > 224) return fail(CNERF_EINVAL, "C=%d must be a multiple of 32 in [32,224]", c->C);
+    if (c->n_levels < 0 || c->n_levels > CNERF_MAX_LEVELS) return fail(CNERF_EINVAL, "n_levels=%d out of range", c->n_levels);
+    if (c->n_levels > 1 || (c->n_levels == 1 && (c->level_V[0] != c->V || c->level_C[0] != c->C))) {
+        int sum = 0;
+        for (int i = 0; i < c->n_levels; ++i) {
+            if (c->level_V[i] < 2 || c->level_V[i] > 1024) return fail(CNERF_EINVAL, "level_V[%d]=%d out of range [2,1024]", i, c->level_V[i]);
+            if (c->level_C[i] < 32 || c->level_C[i] % 32 != 0) return fail(CNERF_EINVAL, "level_C[%d]=%d must be a multiple of 32", i, c->level_C[i]);
+            sum += c->level_C[i];
+        }
+        if (sum != c->C) return fail(CNERF_EINVAL, "sum of level_C (%d) != C (%d)", sum, c->C);
+    }
     if (c->H != 64 && c->H != 128 && c->H != 256) return fail(CNERF_EINVAL, "H=%d must be 64, 128 or 256", c->H);
     if (c->V < 2 || c->V > 1024) return fail(CNERF_EINVAL, "V=%d out of range [2,1024]", c->V);
     if (c->L < 1 || c->L > CNERF_MAX_LAYERS) return fail(CNERF_EINVAL, "L=%d out of range [1,%d]", c->L, CNERF_MAX_LAYERS);
@@ -55,14 +65,22 @@ struct PackedLayout {
     size_t weight_floats;
     size_t bias_floats;
     int n_film;
+    int n_in;      // 32-wide input tiles of layer 0
+    int k0;        // real input width of layer 0
 };
+
+int n_levels_of(const cnerf_cfg* c) { return c->n_levels > 0 ? c->n_levels : 1; }
+int level_V_of(const cnerf_cfg* c, int i) { return c->n_levels > 0 ? c->level_V[i] : c->V; }
+int level_C_of(const cnerf_cfg* c, int i) { return c->n_levels > 0 ? c->level_C[i] : c->C; }
 
 PackedLayout packed_layout(const cnerf_cfg* c) {
     const size_t NT = c->H / 32;
     const size_t tile = 4 * 64 * 4;  // floats per (t, tk) pair
-    PackedLayout p{0, 0, 0};
+    PackedLayout p{0, 0, 0, 0, 0};
+    p.n_in = c->C / 32 + ((c->flags & CNERF_F_INPUT_XYZ) ? 1 : 0);
+    p.k0 = c->C + ((c->flags & CNERF_F_INPUT_XYZ) ? 3 : 0);
     for (int l = 0; l < c->L; ++l) {
-        const size_t kt = (l == 0) ? 1 : NT;
+        const size_t kt = (l == 0) ? (size_t)p.n_in : NT;
         if (c->layer_kind[l] == CNERF_LAYER_RES) {
             p.weight_floats += 2 * NT * NT * tile;
             p.bias_floats += 2 * c->H;
@@ -88,11 +106,36 @@ RayGeom make_geom(const cnerf_cfg* c) {
     return g;
 }
 
-void fill_field_args(FieldArgs& a, const cnerf_cfg* c, const float* fvol_cl, const float* packed, const float* freq,
-                     const float* phase) {
+// image0: first image of the sub-range this launch works on (per-image pointers are offset here)
+int fill_field_args(FieldArgs& a, const cnerf_cfg* c, const cnerf_volumes* vols, const cnerf_grad_volumes* gvols,
+                    const float* packed, const float* freq, const float* phase, int image0 = 0) {
     memset(&a, 0, sizeof(a));
     const PackedLayout pl = packed_layout(c);
-    a.fvol = fvol_cl;
+    if (!vols) return fail(CNERF_EINVAL, "volumes are NULL");
+    int tk = 0;
+    for (int i = 0; i < n_levels_of(c); ++i) {
+        const int V = level_V_of(c, i), C = level_C_of(c, i);
+        if (!vols->level[i]) return fail(CNERF_EINVAL, "volume level %d is NULL", i);
+        const size_t per_image = (size_t)V * V * V * C;
+        a.lvl_vol[i] = vols->level[i] + (size_t)image0 * per_image;
+        a.lvl_grad[i] = (gvols && gvols->level[i]) ? gvols->level[i] + (size_t)image0 * per_image : nullptr;
+        a.lvl_V[i] = V;
+        a.lvl_C[i] = C;
+        for (int cc = 0; cc < C; cc += 32, ++tk) {
+            if (tk >= 8) return fail(CNERF_EINVAL, "more than 8 input tiles");
+            a.in_level[tk] = i;
+            a.in_chan[tk] = cc;
+        }
+    }
+    if (c->flags & CNERF_F_INPUT_XYZ) {
+        if (tk >= 8) return fail(CNERF_EINVAL, "more than 8 input tiles");
+        a.in_level[tk] = -1;
+        a.in_chan[tk] = 0;
+        ++tk;
+    }
+    a.n_in = tk;
+    freq = (pl.n_film && freq) ? freq + (size_t)image0 * pl.n_film * c->H : freq;
+    phase = (pl.n_film && phase) ? phase + (size_t)image0 * pl.n_film * c->H : phase;
     a.packed = packed;
     a.bias = packed + pl.weight_floats;
     a.freq = pl.n_film ? freq : nullptr;
@@ -101,10 +144,10 @@ void fill_field_args(FieldArgs& a, const cnerf_cfg* c, const float* fvol_cl, con
     a.bias_floats = (int)pl.bias_floats;
     a.geom = make_geom(c);
     a.half_voxel = c->voxel_length / 2.0f;
-    a.V = c->V;
     a.L = c->L;
     a.flags = c->flags;
     for (int l = 0; l < c->L; ++l) a.layer_kind[l] = c->layer_kind[l];
+    return CNERF_OK;
 }
 
 void set_points(FieldArgs& a, int B, long long n_per_image) {
@@ -126,7 +169,12 @@ int cnerf_workspace_bytes(const cnerf_cfg* cfg, size_t* packed, size_t* fvol_cl,
     if (int rc = check_cfg(cfg, fwd_ws != nullptr)) return rc;
     const PackedLayout pl = packed_layout(cfg);
     if (packed) *packed = align256((pl.weight_floats + pl.bias_floats + 2 * (size_t)cfg->H) * sizeof(float));
-    if (fvol_cl) *fvol_cl = align256((size_t)cfg->B * cfg->V * cfg->V * cfg->V * cfg->C * sizeof(float));
+    if (fvol_cl) {   // all levels together
+        size_t fl = 0;
+        for (int i = 0; i < n_levels_of(cfg); ++i)
+            fl += (size_t)cfg->B * level_V_of(cfg, i) * level_V_of(cfg, i) * level_V_of(cfg, i) * level_C_of(cfg, i);
+        *fvol_cl = align256(fl * sizeof(float));
+    }
     if (fwd_ws) {
         const size_t N = (size_t)cfg->B * cfg->R * cfg->R * cfg->S;
         // coarse rgb_sigma + z, fine z + rgb_sigma
@@ -137,14 +185,14 @@ int cnerf_workspace_bytes(const cnerf_cfg* cfg, size_t* packed, size_t* fvol_cl,
 
 int cnerf_fvol_channel_last(int32_t B, int32_t C, int32_t V, const float* fvol_cf, float* fvol_cl, void* stream) {
     g_err[0] = 0;
-    if (B < 1 || V < 1 || C != 32 || !fvol_cf || !fvol_cl) return fail(CNERF_EINVAL, "fvol_channel_last: bad argument (C must be 32)");
+    if (B < 1 || V < 1 || C < 32 || C % 32 || !fvol_cf || !fvol_cl) return fail(CNERF_EINVAL, "fvol_channel_last: bad argument (C must be a multiple of 32)");
     if (hipError_t e = launch_transpose_cl(B, C, V, fvol_cf, fvol_cl, true, (hipStream_t)stream)) return hip_fail(e, "transpose");
     return CNERF_OK;
 }
 
 int cnerf_fvol_channel_first(int32_t B, int32_t C, int32_t V, const float* fvol_cl, float* fvol_cf, void* stream) {
     g_err[0] = 0;
-    if (B < 1 || V < 1 || C != 32 || !fvol_cf || !fvol_cl) return fail(CNERF_EINVAL, "fvol_channel_first: bad argument (C must be 32)");
+    if (B < 1 || V < 1 || C < 32 || C % 32 || !fvol_cf || !fvol_cl) return fail(CNERF_EINVAL, "fvol_channel_first: bad argument (C must be a multiple of 32)");
     if (hipError_t e = launch_transpose_cl(B, C, V, fvol_cl, fvol_cf, false, (hipStream_t)stream)) return hip_fail(e, "transpose");
     return CNERF_OK;
 }
@@ -160,10 +208,10 @@ int cnerf_pack_field(const cnerf_cfg* cfg, const cnerf_field_params* p, float* p
     float* bdst = packed + pl.weight_floats;
     const size_t tile = 4 * 64 * 4;
     for (int l = 0; l < cfg->L; ++l) {
-        const int K = (l == 0) ? cfg->C : H;
+        const int K = (l == 0) ? pl.k0 : H;                    // layer 0: C (+3), zero padded to 32 * n_in columns
         if (!p->w[l] || !p->b[l]) return fail(CNERF_EINVAL, "pack_field: layer %d weight/bias is NULL", l);
         if (hipError_t e = launch_pack_matrix(p->w[l], H, K, NT, wdst, stream)) return hip_fail(e, "pack_matrix");
-        wdst += (size_t)NT * (K / 32) * tile;
+        wdst += (size_t)NT * ((K + 31) / 32) * tile;
         if (hipError_t e = hipMemcpyAsync(bdst, p->b[l], H * sizeof(float), hipMemcpyDeviceToDevice, stream)) return hip_fail(e, "bias copy");
         bdst += H;
         if (cfg->layer_kind[l] == CNERF_LAYER_RES) {
@@ -188,20 +236,21 @@ int cnerf_gather_features(const cnerf_cfg* cfg, const float* fvol_cl, const floa
     g_err[0] = 0;
     if (int rc = check_cfg(cfg, false)) return rc;
     if (!fvol_cl || !points || !feat || n_per_image < 1) return fail(CNERF_EINVAL, "gather_features: bad argument");
+    if (cfg->C != 32 || cfg->n_levels > 1) return fail(CNERF_EINVAL, "gather_features: single 32-channel volume only");
     GatherArgs a{fvol_cl, points, feat, (long long)n_per_image, cfg->B, cfg->V, cfg->C, cfg->voxel_length / 2.0f};
     if (hipError_t e = launch_gather(a, (hipStream_t)stream)) return hip_fail(e, "gather");
     return CNERF_OK;
 }
 
-int cnerf_field_forward(const cnerf_cfg* cfg, const float* fvol_cl, const float* packed, const float* freq,
+int cnerf_field_forward(const cnerf_cfg* cfg, const cnerf_volumes* vols, const float* packed, const float* freq,
                         const float* phase, const float* points, int64_t n_per_image, float* rgb_sigma, void* stream) {
     g_err[0] = 0;
     if (int rc = check_cfg(cfg, false)) return rc;
-    if (!fvol_cl || !packed || !points || !rgb_sigma || n_per_image < 1) return fail(CNERF_EINVAL, "field_forward: bad argument");
+    if (!vols || !packed || !points || !rgb_sigma || n_per_image < 1) return fail(CNERF_EINVAL, "field_forward: bad argument");
     const PackedLayout pl = packed_layout(cfg);
     if (pl.n_film && (!freq || !phase)) return fail(CNERF_EINVAL, "field_forward: FiLM layers need freq and phase");
     FieldArgs a;
-    fill_field_args(a, cfg, fvol_cl, packed, freq, phase);
+    if (int rc = fill_field_args(a, cfg, vols, nullptr, packed, freq, phase)) return rc;
     a.mode = FIELD_MODE_POINTS;
     a.points = points;
     a.rgb_sigma = rgb_sigma;
@@ -228,12 +277,12 @@ int cnerf_resample(int64_t rays, int32_t S, const float* z, const float* weights
     return CNERF_OK;
 }
 
-int cnerf_render_forward(const cnerf_cfg* cfg, const float* fvol_cl, const float* packed, const float* freq,
+int cnerf_render_forward(const cnerf_cfg* cfg, const cnerf_volumes* vols, const float* packed, const float* freq,
                          const float* phase, const float* cam2world, const cnerf_rng* rng, float* pixels,
                          float* depth, const cnerf_aux* aux, void* workspace, void* stream_) {
     g_err[0] = 0;
     if (int rc = check_cfg(cfg, true)) return rc;
-    if (!fvol_cl || !packed || !cam2world || !pixels || !depth || !workspace) return fail(CNERF_EINVAL, "render_forward: NULL argument");
+    if (!vols || !packed || !cam2world || !pixels || !depth || !workspace) return fail(CNERF_EINVAL, "render_forward: NULL argument");
     const PackedLayout pl = packed_layout(cfg);
     if (pl.n_film && (!freq || !phase)) return fail(CNERF_EINVAL, "render_forward: FiLM layers need freq and phase");
     const bool hier = cfg->flags & CNERF_F_HIERARCHICAL;
@@ -258,7 +307,7 @@ int cnerf_render_forward(const cnerf_cfg* cfg, const float* fvol_cl, const float
     }
 
     FieldArgs fa;
-    fill_field_args(fa, cfg, fvol_cl, packed, freq, phase);
+    if (int rc = fill_field_args(fa, cfg, vols, nullptr, packed, freq, phase)) return rc;
     set_points(fa, cfg->B, npi);
     fa.cam2world = cam2world;
     // 1. coarse pass
@@ -309,7 +358,7 @@ int cnerf_backward_bytes(const cnerf_cfg* cfg, size_t* packed_t) {
     const size_t NT = cfg->H / 32, tile = 4 * 64 * 4;
     size_t fl = NT * 2 * 64;                                  // head^T
     for (int l = cfg->L - 1; l >= 1; --l) fl += NT * NT * tile;
-    fl += NT * tile;                                          // layer 0 transposed: one 32-row output tile
+    fl += (size_t)packed_layout(cfg).n_in * NT * tile;       // layer 0 transposed: one 32-row output tile per input tile
     if (packed_t) *packed_t = align256(fl * sizeof(float));
     return CNERF_OK;
 }
@@ -333,7 +382,8 @@ int cnerf_pack_field_transposed(const cnerf_cfg* cfg, const cnerf_field_params* 
         dst += (size_t)NT * NT * tile;
     }
     if (!p->w[0]) return fail(CNERF_EINVAL, "pack_field_transposed: layer 0 weight is NULL");
-    if (hipError_t e = launch_pack_matrix_t(p->w[0], H, cfg->C, 1, dst, stream)) return hip_fail(e, "pack_matrix_t");
+    const PackedLayout pl = packed_layout(cfg);
+    if (hipError_t e = launch_pack_matrix_t(p->w[0], H, pl.k0, pl.n_in, dst, stream)) return hip_fail(e, "pack_matrix_t");
     return CNERF_OK;
 }
 
@@ -353,30 +403,30 @@ int cnerf_merge_composite_backward(const cnerf_cfg* cfg, const float* coarse_rgb
     return CNERF_OK;
 }
 
-int cnerf_field_backward(const cnerf_cfg* cfg, int32_t pass, int32_t image0, int32_t n_images, const float* fvol_cl,
+int cnerf_field_backward(const cnerf_cfg* cfg, int32_t pass, int32_t image0, int32_t n_images, const cnerf_volumes* vols,
                          const float* packed, const float* packed_t, const float* freq, const float* phase,
                          const float* cam2world, const float* u_strat, const float* fine_z,
                          const float* grad_rgb_sigma, const float* saved_rgb_sigma, float* act_feat, float* act_h,
-                         float* act_c, float* act_g, float* act_go, float* grad_fvol_cl, void* stream_) {
+                         float* act_c, float* act_g, float* act_go, const cnerf_grad_volumes* grad_vols, void* stream_) {
     g_err[0] = 0;
     if (int rc = check_cfg(cfg, true)) return rc;
     for (int l = 0; l < cfg->L; ++l)
         if (cfg->layer_kind[l] == CNERF_LAYER_RES) return fail(CNERF_ENOSYS, "backward through residual blocks is not implemented");
     if (image0 < 0 || n_images < 1 || image0 + n_images > cfg->B) return fail(CNERF_EINVAL, "field_backward: image range out of [0,B)");
     if (pass < 0 || pass > 2) return fail(CNERF_EINVAL, "field_backward: pass must be 0 (coarse), 1 (fine) or 2 (explicit points)");
-    if (!fvol_cl || !packed || !packed_t || !cam2world || !grad_rgb_sigma || !saved_rgb_sigma || !act_feat || !act_h || !act_c ||
-        !act_g || !act_go || !grad_fvol_cl)
+    if (!vols || !packed || !packed_t || !cam2world || !grad_rgb_sigma || !saved_rgb_sigma || !act_feat || !act_h || !act_c ||
+        !act_g || !act_go || !grad_vols)
         return fail(CNERF_EINVAL, "field_backward: NULL argument");
+    for (int i = 0; i < n_levels_of(cfg); ++i)
+        if (!grad_vols->level[i]) return fail(CNERF_EINVAL, "field_backward: gradient volume %d is NULL", i);
     if (pass == 1 && !fine_z) return fail(CNERF_EINVAL, "field_backward: the fine pass needs fine_z");
     const PackedLayout pl = packed_layout(cfg);
     if (pl.n_film && (!freq || !phase)) return fail(CNERF_EINVAL, "field_backward: FiLM layers need freq and phase");
     hipStream_t stream = (hipStream_t)stream_;
     const long long npi = (long long)cfg->R * cfg->R * cfg->S;
-    const size_t vol = (size_t)cfg->V * cfg->V * cfg->V * 32;
 
     FieldArgs fa;
-    fill_field_args(fa, cfg, fvol_cl + (size_t)image0 * vol, packed, pl.n_film ? freq + (size_t)image0 * pl.n_film * cfg->H : nullptr,
-                    pl.n_film ? phase + (size_t)image0 * pl.n_film * cfg->H : nullptr);
+    if (int rc = fill_field_args(fa, cfg, vols, grad_vols, packed, freq, phase, image0)) return rc;
     set_points(fa, n_images, npi);
     fa.cam2world = cam2world + (size_t)image0 * 16;
     if (pass == 0) {
@@ -402,7 +452,6 @@ int cnerf_field_backward(const cnerf_cfg* cfg, int32_t pass, int32_t image0, int
     fa.saved_out = saved_rgb_sigma + (size_t)image0 * npi * 4;
     fa.act_g = act_g;
     fa.act_go = act_go;
-    fa.grad_fvol = grad_fvol_cl + (size_t)image0 * vol;
     if (hipError_t e = launch_field_backward(fa, cfg->H, stream)) return hip_fail(e, "field backward kernel");
     return CNERF_OK;
 }

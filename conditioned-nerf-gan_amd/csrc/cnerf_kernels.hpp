@@ -12,7 +12,15 @@ enum { FIELD_MODE_POINTS = 0, FIELD_MODE_COARSE = 1, FIELD_MODE_FINE = 2 };
 
 // Arguments of field_tile_kernel (passed by value).
 struct FieldArgs {
-    const float* fvol;       // (B,V,V,V,32) channel-last
+    // layer-0 inputs: n_in tiles of 32 channels; in_level[tk] = pyramid level (or -1: the xyz tile), in_chan[tk] = first
+    // channel inside that level.  lvl_vol: (B,V,V,V,C) channel-last; lvl_grad: same shape, backward only.
+    int n_in;
+    int in_level[8];
+    int in_chan[8];
+    const float* lvl_vol[CNERF_MAX_LEVELS];
+    float* lvl_grad[CNERF_MAX_LEVELS];
+    int lvl_V[CNERF_MAX_LEVELS];
+    int lvl_C[CNERF_MAX_LEVELS];
     const float* packed;     // packed weights (float4 stream, see field_kernel.hip)
     const float* bias;       // biases of all layers then the head, inside the packed buffer
     const float* freq;       // (B, film_stride) or null
@@ -27,7 +35,7 @@ struct FieldArgs {
     unsigned long long* stamps;  // diagnostic builds (-DCNERF_STAMPS) only: 8 cycle totals; else unused
     // activation store of the backward pass (all null in a plain forward): row-major [point][channel]
     long long act_points;    // rows of every activation buffer (= B * n_per_image of the chunk)
-    float* act_feat;         // (n,32) looked-up features
+    float* act_feat;         // (n,32*n_in) layer-0 input tiles (looked-up features, xyz)
     float* act_h;            // (L,n,H) layer outputs sin(arg)
     float* act_c;            // (L,n,H) cos(arg)
     // field_backward_kernel only
@@ -36,13 +44,11 @@ struct FieldArgs {
     const float* saved_out;  // (n,4) rgb_sigma of the forward (sigmoid')
     float* act_g;            // (L,n,H) d loss / d arg
     float* act_go;           // (n,4)   d loss / d head pre-activation
-    float* grad_fvol;        // (V,V,V,32) of this image, accumulated with atomics
     long long n_per_image;
     long long tiles_per_image;
     long long total_tiles;
     RayGeom geom;
     float half_voxel;
-    int V;
     int L;
     int film_stride;
     int bias_floats;         // biases of all layers + head (padded to 4): ones[H], zeros[H] follow
@@ -52,7 +58,7 @@ struct FieldArgs {
 };
 
 hipError_t launch_fill(float* dst, float value, int n, hipStream_t stream);
-hipError_t launch_pack_matrix(const float* w, int n_out, int K, int OT, float* dst, hipStream_t stream);
+hipError_t launch_pack_matrix(const float* w, int n_out, int K_real, int OT, float* dst, hipStream_t stream);
 hipError_t launch_field(const FieldArgs& a, int H, hipStream_t stream);
 hipError_t launch_field_backward(const FieldArgs& a, int H, hipStream_t stream);
 hipError_t launch_pack_head_t(const float* w, int H, float* dst, hipStream_t stream);

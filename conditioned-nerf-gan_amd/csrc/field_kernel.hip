@@ -24,8 +24,8 @@ namespace cnerf {
 // matrix with K inputs (K = 32*KT) and 32*OT outputs: float4 index ((t*KT + tk)*4 + g)*64 + lane
 //   value[e] = W[32t + (lane&31)][32tk + 8g + 4(lane>>5) + e]     (rows >= n_out are zero: the head has 4 rows)
 
-__global__ void pack_matrix_kernel(const float* __restrict__ w, int n_out, int K, int OT, float* __restrict__ dst) {
-    const int KT = K / 32;
+__global__ void pack_matrix_kernel(const float* __restrict__ w, int n_out, int K_real, int K, int OT, float* __restrict__ dst) {
+    const int KT = K / 32;          // K = K_real padded to a multiple of 32 (columns >= K_real are zero)
     const int total = OT * KT * 4 * 64 * 4;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
         const int e = idx & 3;
@@ -35,7 +35,7 @@ __global__ void pack_matrix_kernel(const float* __restrict__ w, int n_out, int K
         const int tk = rest % KT, t = rest / KT;
         const int row = 32 * t + (lane & 31);
         const int col = 32 * tk + 8 * g + 4 * (lane >> 5) + e;
-        dst[idx] = (row < n_out) ? w[(size_t)row * K + col] : 0.0f;
+        dst[idx] = (row < n_out && col < K_real) ? w[(size_t)row * K_real + col] : 0.0f;
     }
 }
 
@@ -169,6 +169,89 @@ __device__ __forceinline__ void mlp_matrix(const f32x4* __restrict__ wp, const f
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Layer-0 input tiles.  The input of layer 0 is a runtime list of 32-wide tiles: 32 channels of one pyramid level's
+// feature volume (siren.py:555-571, 1444-1473) or the world position padded to 32 (feature || xyz, siren.py:1158).
+// Lane (j, h) holds channels 8g + 4h + e of its point in register 4g + e, like every activation tile.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ f32x16 input_tile(const FieldArgs& a, int b, int tk, float px, float py, float pz, int h) {
+    f32x16 feat;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) feat[r] = 0.0f;
+    const int lvl = a.in_level[tk];
+    if (lvl < 0) {                       // xyz tile: channels 0,1,2 = x,y,z live in half 0, registers 0..2
+        if (h == 0) {
+            feat[0] = px;
+            feat[1] = py;
+            feat[2] = pz;
+        }
+        return feat;
+    }
+    const int V = a.lvl_V[lvl], C = a.lvl_C[lvl];
+    Corner8 cr;
+    trilinear_corners(px, py, pz, a.half_voxel, V, cr);
+    const float* vol = a.lvl_vol[lvl] + (size_t)b * V * V * V * C + a.in_chan[tk] + 4 * h;
+    f32x4 q[8][4];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float* cp = vol + (size_t)cr.base[k] * C;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) q[k][g] = *reinterpret_cast<const f32x4*>(cp + 8 * g);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k)     // ATen order: corners sequentially, product and sum rounded separately
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) feat[4 * g + e] = feat[4 * g + e] + q[k][g][e] * cr.w[k];
+    return feat;
+}
+
+// y[t] += W0[t, tile tk] * feat   for all NT output tiles (k-outer form of layer 0: any number of input tiles)
+template <int NT>
+__device__ __forceinline__ void layer0_accumulate(const f32x4* __restrict__ wp, int n_in, int tk, const f32x16& feat,
+                                                  f32x16* y, int lane) {
+    constexpr int NG = NT * 4;
+    auto addr = [&](int i) { return wp + ((size_t)((i >> 2) * n_in + tk) * 4 + (i & 3)) * 64 + lane; };
+    f32x4 ring[RING];
+#pragma unroll
+    for (int i = 0; i < RING; ++i)
+        if (i < NG) ring[i] = *addr(i);
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+        const int t = i >> 2, g = i & 3;
+        const f32x4 aw = ring[i % RING];
+        if (i + RING < NG) ring[i % RING] = *addr(i + RING);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[e], feat[4 * g + e], y[t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// x[t] = sin(freq * y[t] + phase) for all tiles (+ activation store)
+template <int NT, bool STORE>
+__device__ __forceinline__ void film_all(const f32x16* y, f32x16* x, const float* __restrict__ freq,
+                                         const float* __restrict__ phase, int h, float* row_h, float* row_c) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const f32x16 fr = load_chan16(freq, t, h);
+        const f32x16 ph = load_chan16(phase, t, h);
+        f32x16 o, cs;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float c_ = 0.0f;
+            o[r] = epilogue_one<EPI_FILM, STORE>(y[t][r], 0.0f, fr[r], ph[r], c_);
+            if (STORE) cs[r] = c_;
+        }
+        x[t] = o;
+        if (STORE) {
+            store_tile_rows(row_h, t, h, o);
+            store_tile_rows(row_c, t, h, cs);
+        }
+    }
+}
+
 #ifdef CNERF_STAMPS
 // Diagnostic build only: per-phase cycle totals (s_memtime) summed over all tiles of all waves into a.stamps[0..7].
 #define STAMP(i)                                                                                     \
@@ -256,63 +339,44 @@ __global__ __launch_bounds__(256) void field_tile_kernel(FieldArgs a) {
         float px, py, pz;
         tile_point(a, b, nn, valid, h, true, px, py, pz);
 
-        // ---- trilinear lookup: this lane's 16 of the 32 channels (8g + 4h + e) ---------------------------------------
-        Corner8 cr;
-        trilinear_corners(px, py, pz, a.half_voxel, a.V, cr);
-        const float* vol = a.fvol + (size_t)b * a.V * a.V * a.V * 32 + 4 * h;
-        f32x16 feat;
-        {
-            f32x4 q[8][4];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const float* cp = vol + (size_t)cr.base[k] * 32;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) q[k][g] = *reinterpret_cast<const f32x4*>(cp + 8 * g);
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) feat[r] = 0.0f;
-#pragma unroll
-            for (int k = 0; k < 8; ++k)     // ATen order: corners sequentially, product and sum rounded separately
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) feat[4 * g + e] = feat[4 * g + e] + q[k][g][e] * cr.w[k];
-        }
-
-        asm volatile("" :: "v"(feat[0]), "v"(feat[15]));
-        STAMP(1);   // position + gather
-        // ---- MLP ---------------------------------------------------------------------------------------------------
+        // ---- layer 0: lookups feed the matrix pipe tile by tile ---------------------------------------------------------
         // A plain sine layer is a FiLM layer with freq = 1, phase = 0 (1*x and +0 are exact): one code path.
         Act<NT> x, y;
         const size_t gpt = (size_t)b * a.n_per_image + nn;                 // global point row of the activation buffers
         const size_t act_layer = (size_t)a.act_points * H;                 // floats per layer in act_h / act_c
         float* row_h = STORE ? a.act_h + gpt * H : nullptr;
         float* row_c = STORE ? a.act_c + gpt * H : nullptr;
-        if (STORE) {
-            float* fo = a.act_feat + gpt * 32 + 4 * h;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                f32x4 q;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) q[e] = feat[4 * g + e];
-                *reinterpret_cast<f32x4*>(fo + 8 * g) = q;
-            }
-        }
         const f32x4* wp = reinterpret_cast<const f32x4*>(a.packed);
         const float* bias = a.bias;              // concatenated biases, layer after layer (H each, RES: 2H)
         const float* ones = a.bias + a.bias_floats;
         const float* zeros = ones + H;
         const float* freq = a.freq ? a.freq + (size_t)b * a.film_stride : nullptr;
         const float* phase = a.phase ? a.phase + (size_t)b * a.film_stride : nullptr;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) y.v[t] = load_chan16(bias, t, h);
+        for (int tk = 0; tk < a.n_in; ++tk) {
+            const f32x16 feat = input_tile(a, b, tk, px, py, pz, h);
+            if (STORE) {
+                float* fo = a.act_feat + gpt * (32 * a.n_in) + 32 * tk + 4 * h;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 q;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) q[e] = feat[4 * g + e];
+                    *reinterpret_cast<f32x4*>(fo + 8 * g) = q;
+                }
+            }
+            layer0_accumulate<NT>(wp, a.n_in, tk, feat, y.v, lane);
+        }
+        STAMP(1);   // position + lookups + layer-0 products
         {
             const bool film = a.layer_kind[0] == CNERF_LAYER_FILM;
-            mlp_matrix<NT, 1, EPI_FILM, STORE>(wp, bias, film ? freq : ones, film ? phase : zeros, &feat, nullptr, x.v, lane, h,
-                                               row_h, row_c);
+            film_all<NT, STORE>(y.v, x.v, film ? freq : ones, film ? phase : zeros, h, row_h, row_c);
             if (STORE) {
                 row_h += act_layer;
                 row_c += act_layer;
             }
-            wp += (size_t)NT * TILE4;
+            wp += (size_t)NT * a.n_in * TILE4;
             bias += H;
             if (film) {
                 freq += H;
@@ -320,7 +384,7 @@ __global__ __launch_bounds__(256) void field_tile_kernel(FieldArgs a) {
             }
         }
         asm volatile("" :: "v"(x.v[0][0]), "v"(x.v[NT - 1][15]));
-        STAMP(2);   // layer 0
+        STAMP(2);   // layer 0 epilogue
         for (int l = 1; l < a.L; ++l) {
             const int kind = a.layer_kind[l];
             if (!HAS_RES || kind != CNERF_LAYER_RES) {
@@ -527,41 +591,44 @@ __global__ __launch_bounds__(256) void field_backward_kernel(FieldArgs a) {
                 for (int t = 0; t < NT; ++t) g.v[t] = g2.v[t];
             }
         }
-        // ---- first layer: 32 feature channels ----------------------------------------------------------------------------
-        f32x16 gfeat;
-        bwd_matrix<1, NT>(wp, g.v, &gfeat, lane);
-
-        // ---- trilinear scatter-add ----------------------------------------------------------------------------------------
+        // ---- layer 0: one 32-channel gradient tile per input tile; feature tiles are scattered, the xyz tile is dropped ----
         float px, py, pz;
         tile_point(a, b, nn, valid, h, false, px, py, pz);
-        Corner8 cr;
-        trilinear_corners(px, py, pz, a.half_voxel, a.V, cr);
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) s_g[wv][j][8 * gq + 4 * h + e] = gfeat[4 * gq + e];
-        if (h == 0) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                s_base[wv][j][k] = cr.base[k];
-                s_w[wv][j][k] = valid ? cr.w[k] : 0.0f;
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        float* gv = a.grad_fvol + (size_t)b * a.V * a.V * a.V * 32;
         const int ch = lane & 31;
-        for (int pp = 0; pp < 16; ++pp) {
-            const int p = 2 * pp + h;                      // two points per wave instruction, 32 channels each
-            const float gval = s_g[wv][p][ch];
+        for (int tk = 0; tk < a.n_in; ++tk) {
+            const int lvl = a.in_level[tk];
+            if (lvl < 0) continue;                              // no gradient flows to the sample positions
+            f32x16 gfeat;
+            bwd_matrix<1, NT>(wp + (size_t)tk * NT * TILE4, g.v, &gfeat, lane);
+            const int V = a.lvl_V[lvl], C = a.lvl_C[lvl];
+            Corner8 cr;
+            trilinear_corners(px, py, pz, a.half_voxel, V, cr);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const float wk = s_w[wv][p][k];
-                if (wk != 0.0f) atomicAdd(gv + (size_t)s_base[wv][p][k] * 32 + ch, gval * wk);
+            for (int gq = 0; gq < 4; ++gq)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s_g[wv][j][8 * gq + 4 * h + e] = gfeat[4 * gq + e];
+            if (h == 0) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    s_base[wv][j][k] = cr.base[k];
+                    s_w[wv][j][k] = valid ? cr.w[k] : 0.0f;
+                }
             }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            float* gv = a.lvl_grad[lvl] + (size_t)b * V * V * V * C + a.in_chan[tk];
+            for (int pp = 0; pp < 16; ++pp) {
+                const int p = 2 * pp + h;                      // two points per wave instruction, 32 channels each
+                const float gval = s_g[wv][p][ch];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float wk = s_w[wv][p][k];
+                    if (wk != 0.0f) atomicAdd(gv + (size_t)s_base[wv][p][k] * C + ch, gval * wk);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -580,9 +647,9 @@ __global__ void pack_matrix_t_kernel(const float* __restrict__ w, int n_rows_w, 
         const int g = (idx >> 8) & 3;
         const int rest = idx >> 10;
         const int tk = rest % KT, t = rest / KT;
-        const int mrow = 32 * t + (lane & 31);                       // column of W
+        const int mrow = 32 * t + (lane & 31);                       // column of W (>= n_cols_w: padding)
         const int mcol = 32 * tk + 8 * g + 4 * (lane >> 5) + e;      // row of W
-        dst[idx] = w[(size_t)mcol * n_cols_w + mrow];
+        dst[idx] = (mrow < n_cols_w) ? w[(size_t)mcol * n_cols_w + mrow] : 0.0f;
     }
 }
 
@@ -618,10 +685,11 @@ hipError_t launch_fill(float* dst, float value, int n, hipStream_t stream) {
     return hipGetLastError();
 }
 
-hipError_t launch_pack_matrix(const float* w, int n_out, int K, int OT, float* dst, hipStream_t stream) {
+hipError_t launch_pack_matrix(const float* w, int n_out, int K_real, int OT, float* dst, hipStream_t stream) {
+    const int K = (K_real + 31) / 32 * 32;
     const int total = OT * (K / 32) * 4 * 64 * 4;
     const int blocks = (total + 255) / 256;
-    hipLaunchKernelGGL(pack_matrix_kernel, dim3(blocks), dim3(256), 0, stream, w, n_out, K, OT, dst);
+    hipLaunchKernelGGL(pack_matrix_kernel, dim3(blocks), dim3(256), 0, stream, w, n_out, K_real, K, OT, dst);
     return hipGetLastError();
 }
 

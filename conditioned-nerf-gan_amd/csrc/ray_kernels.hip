@@ -466,14 +466,15 @@ __global__ __launch_bounds__(256) void merge_composite_backward_kernel(MergeBwdA
 // (B,C,V^3) <-> (B,V^3,C), C == 32: tiles of 32 channels x 64 voxels through LDS
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void transpose_cl_kernel(const float* __restrict__ src, float* __restrict__ dst,
-                                                           long long V3, int to_channel_last) {
+                                                           long long V3, int C, int to_channel_last) {
     __shared__ float tile[32][65];
     const int b = blockIdx.y;
+    const int cb = blockIdx.z * 32;                 // this block's group of 32 channels
     const long long v0 = (long long)blockIdx.x * 64;
     const int t = threadIdx.x;
-    const float* s = src + (size_t)b * 32 * V3;
-    float* d = dst + (size_t)b * 32 * V3;
     if (to_channel_last) {
+        const float* s = src + ((size_t)b * C + cb) * V3;
+        float* d = dst + (size_t)b * C * V3 + cb;
         const int vv = t & 63, c0 = t >> 6;
 #pragma unroll
         for (int c = 0; c < 32; c += 4)
@@ -482,12 +483,14 @@ __global__ __launch_bounds__(256) void transpose_cl_kernel(const float* __restri
         const int cc = t & 31, w0 = t >> 5;
 #pragma unroll
         for (int k = 0; k < 64; k += 8)
-            if (v0 + k + w0 < V3) d[(size_t)(v0 + k + w0) * 32 + cc] = tile[cc][k + w0];
+            if (v0 + k + w0 < V3) d[(size_t)(v0 + k + w0) * C + cc] = tile[cc][k + w0];
     } else {
+        const float* s = src + (size_t)b * C * V3 + cb;
+        float* d = dst + ((size_t)b * C + cb) * V3;
         const int cc = t & 31, w0 = t >> 5;
 #pragma unroll
         for (int k = 0; k < 64; k += 8)
-            if (v0 + k + w0 < V3) tile[cc][k + w0] = s[(size_t)(v0 + k + w0) * 32 + cc];
+            if (v0 + k + w0 < V3) tile[cc][k + w0] = s[(size_t)(v0 + k + w0) * C + cc];
         __syncthreads();
         const int vv = t & 63, c0 = t >> 6;
 #pragma unroll
@@ -544,10 +547,10 @@ hipError_t launch_merge_composite_backward(const MergeBwdArgs& a, hipStream_t st
 }
 hipError_t launch_transpose_cl(int B, int C, int V, const float* src, float* dst, bool to_channel_last,
                                hipStream_t stream) {
-    if (C != 32) return hipErrorInvalidValue;
+    if (C < 32 || C % 32 != 0) return hipErrorInvalidValue;
     const long long V3 = (long long)V * V * V;
-    dim3 grid((unsigned)((V3 + 63) / 64), (unsigned)B);
-    hipLaunchKernelGGL(transpose_cl_kernel, grid, dim3(256), 0, stream, src, dst, V3, to_channel_last ? 1 : 0);
+    dim3 grid((unsigned)((V3 + 63) / 64), (unsigned)B, (unsigned)(C / 32));
+    hipLaunchKernelGGL(transpose_cl_kernel, grid, dim3(256), 0, stream, src, dst, V3, C, to_channel_last ? 1 : 0);
     return hipGetLastError();
 }
 hipError_t launch_gather(const GatherArgs& a, hipStream_t stream) {

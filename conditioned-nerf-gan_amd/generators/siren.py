@@ -23,6 +23,7 @@ class FieldSpec:
     sigmoid_rgb: bool           # _sigmoid_rgb on the head                      (siren.py:1227-1234)
     has_global: bool            # z = (feature_volume, global_feature)
     input_is_zdim: bool = False  # the dRes family overrides input_dim = z_dim  (siren.py:349)
+    input: str = "feat"         # "feat" | "feat_xyz" (siren.py:1158) | "pyramid" (siren.py:1444-1473)
 
 
 FIELD_SPECS = {
@@ -34,6 +35,8 @@ FIELD_SPECS = {
     "SHORTSIREN_FRes": FieldSpec(("sine", "res", "sine"), 12, True, False),
     "TALLSIREN_dRes": FieldSpec(("sine", "res", "res", "sine"), 25, False, False, True),
     "TALLSIREN_dResLong": FieldSpec(("sine",) + ("res",) * 4 + ("sine",), 25, False, False, True),
+    "TALLSIREN_dgx": FieldSpec(("film",) * 8, 25, False, True, False, "feat_xyz"),
+    "SHORTSIREN_FG_Pyrmd": FieldSpec(("film",) * 4, 12, True, True, False, "pyramid"),
 }
 
 
@@ -109,12 +112,10 @@ class FieldNetwork(nn.Module):
 
     # -- pieces the renderer needs -------------------------------------------------------------------------------
     def split_z(self, z):
-        """-> (feature_volume (B,C,V,V,V), global_feature or None)."""
+        """-> (feature volume (B,C,V,V,V) or list of pyramid levels, global_feature or None)."""
         if self.spec.has_global:
             fvol, glob = z
             return fvol, glob
-        if isinstance(z, (tuple, list)):
-            return z[0], None
         return z, None
 
     def film(self, global_feature: Optional[torch.Tensor]):
@@ -145,6 +146,51 @@ class FieldNetwork(nn.Module):
         fvol, glob = self.split_z(z)
         freq, phase = self.film(glob)
         return ops.field_forward(self, fvol, freq, phase, points)
+
+
+class PointFeaturesMappingNetwork(nn.Module):
+    """Per-point FiLM parameters from the looked-up feature: Linear -> LeakyReLU(0.2) -> Linear, kaiming-leaky init, last
+    layer scaled by 0.25 (siren.py:47-52, 81-101).  Parameter holder; evaluated inside the field kernel."""
+
+    def __init__(self, z_dim, map_hidden_dim, map_output_dim):
+        super().__init__()
+        self.network = nn.Sequential(nn.Linear(z_dim, map_hidden_dim), nn.LeakyReLU(0.2, inplace=True),
+                                     nn.Linear(map_hidden_dim, map_output_dim))
+        for m in self.network:
+            if isinstance(m, nn.Linear):
+                torch.nn.init.kaiming_normal_(m.weight, a=0.2, mode="fan_in", nonlinearity="leaky_relu")
+        with torch.no_grad():
+            self.network[-1].weight *= 0.25
+
+
+class PointwiseFiLMLayer(_LinearSine):
+    kind = "pfilm"
+
+
+class TALLSIREN(nn.Module):
+    """pi-GAN style field (siren.py:232-331): input = world xyz, eight FiLM layers whose frequencies / phases come per
+    POINT from a mapping MLP of the looked-up feature.  Parameters, names and initialisation mirror the reference so its
+    checkpoints load; the HIP kernel for this family is not written yet, so evaluating it raises NotImplementedError."""
+    variant = "TALLSIREN"
+
+    def __init__(self, input_dim=3, z_dim=100, hidden_dim=256, output_dim=4, drop_out=0, device=None, **kwargs):
+        super().__init__()
+        self.device = device
+        self.input_dim, self.z_dim, self.hidden_dim, self.output_dim = input_dim, z_dim, hidden_dim, output_dim
+        self.drop_out = drop_out
+        self.network = nn.ModuleList([PointwiseFiLMLayer(input_dim if i == 0 else hidden_dim, hidden_dim, drop_out)
+                                      for i in range(8)])
+        self.final_layer = nn.Linear(hidden_dim, 4)
+        self.mapping_network = PointFeaturesMappingNetwork(z_dim, 256, len(self.network) * hidden_dim * 2)
+        _uniform_weights(self.network, lambda n: math.sqrt(6 / n) / 25)
+        _uniform_weights(self.final_layer, lambda n: math.sqrt(6 / n) / 25)
+        _uniform_weights(self.network[0], lambda n: 1 / n)
+
+    def check_supported(self):
+        raise NotImplementedError("TALLSIREN (per-point FiLM mapping network) has no HIP kernel yet")
+
+    def forward(self, points, z, img_size=None, num_steps=None):
+        self.check_supported()
 
 
 def _make(name):

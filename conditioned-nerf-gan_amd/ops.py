@@ -22,12 +22,38 @@ def _f32(t):
     return t.contiguous()
 
 
-def make_cfg(net, B, V, R=1, S=2, fov=30.0, ray_start=0.0, ray_end=1.0, noise_std=0.0, hierarchical=False,
+def as_levels(vols):
+    """Channel-last volume(s) -> list of (B,V,V,V,C) tensors."""
+    return list(vols) if isinstance(vols, (list, tuple)) else [vols]
+
+
+def volumes_struct(levels):
+    v = L.Volumes()
+    for i, t in enumerate(levels):
+        L.ptr(t)
+        v.level[i] = t.data_ptr()
+    return v
+
+
+def make_cfg(net, B, vols, R=1, S=2, fov=30.0, ray_start=0.0, ray_end=1.0, noise_std=0.0, hierarchical=False,
              white_back=False, last_back=False, clamp_mode="relu"):
-    """cnerf_cfg for a field network `net` (generators.siren.FieldNetwork)."""
+    """cnerf_cfg for a field network `net` (generators.siren.FieldNetwork); vols: channel-last volume(s) or, for calls
+    that touch no volume, the side V of a single 32-channel one."""
     cfg = L.Cfg()
-    cfg.B, cfg.R, cfg.S, cfg.V = int(B), int(R), int(S), int(V)
-    cfg.C, cfg.H = int(net.input_dim), int(net.hidden_dim)
+    if isinstance(vols, int):
+        shapes = [(vols, 32)]
+    else:
+        shapes = [(int(t.shape[1]), int(t.shape[-1])) for t in as_levels(vols)]
+    if len(shapes) > L.MAX_LEVELS:
+        raise L.CnerfError(f"at most {L.MAX_LEVELS} feature volumes")
+    cfg.B, cfg.R, cfg.S, cfg.V = int(B), int(R), int(S), shapes[0][0]
+    cfg.C, cfg.H = sum(c for _, c in shapes), int(net.hidden_dim)
+    cfg.n_levels = len(shapes)
+    for i, (v, c) in enumerate(shapes):
+        cfg.level_V[i], cfg.level_C[i] = v, c
+    k0 = cfg.C + (3 if net.spec.input == "feat_xyz" else 0)
+    if not isinstance(vols, int) and k0 != int(net.input_dim):
+        raise L.CnerfError(f"{net.variant}: layer 0 expects {net.input_dim} inputs, the feature volumes provide {k0}")
     kinds = [L.LAYER_CODE[k] for k in net.spec.layers]
     cfg.L = len(kinds)
     for i, k in enumerate(kinds):
@@ -43,6 +69,7 @@ def make_cfg(net, B, V, R=1, S=2, fov=30.0, ray_start=0.0, ray_end=1.0, noise_st
     flags |= L.F_LAST_BACK if last_back else 0
     flags |= L.F_SOFTPLUS if clamp_mode == "softplus" else 0
     flags |= L.F_SIGMOID_RGB if net.spec.sigmoid_rgb else 0
+    flags |= L.F_INPUT_XYZ if net.spec.input == "feat_xyz" else 0
     cfg.flags = flags
     return cfg
 
@@ -76,8 +103,13 @@ def pack_field(net, cfg):
     return packed
 
 
+def channel_last_levels(vols):
+    """Channel-first volume or list of volumes -> list of channel-last volumes."""
+    return [channel_last(v) for v in as_levels(vols)]
+
+
 def channel_last(fvol):
-    """(B,C,V,V,V) -> (B,V,V,V,C) on the GPU."""
+    """(B,C,V,V,V) -> (B,V,V,V,C) on the GPU (C a multiple of 32)."""
     fvol = _f32(fvol)
     B, Cc, V = fvol.shape[0], fvol.shape[1], fvol.shape[-1]
     if fvol.shape[2:] != (V, V, V):
@@ -98,7 +130,7 @@ def channel_first(fvol_cl):
 def gather_features(net, fvol_cl, points):
     points = _f32(points)
     B, n = points.shape[0], points.shape[1]
-    cfg = make_cfg(net, B, fvol_cl.shape[1])
+    cfg = make_cfg(net, B, int(fvol_cl.shape[1]))
     out = torch.empty((B, n, fvol_cl.shape[-1]), dtype=torch.float32, device=points.device)
     L.check(L.lib().cnerf_gather_features(C.byref(cfg), L.ptr(fvol_cl), L.ptr(points), n, L.ptr(out), _stream()),
             "cnerf_gather_features")
@@ -109,11 +141,12 @@ def field_forward(net, fvol, freq, phase, points, fvol_is_channel_last=False):
     """rgb_sigma (B,n,4) of `net` at explicit world points (B,n,3)."""
     points = _f32(points)
     B, n = points.shape[0], points.shape[1]
-    fvol_cl = _f32(fvol) if fvol_is_channel_last else channel_last(fvol)
-    cfg = make_cfg(net, B, fvol_cl.shape[1])
+    levels = [_f32(v) for v in as_levels(fvol)] if fvol_is_channel_last else channel_last_levels(fvol)
+    cfg = make_cfg(net, B, levels)
     packed = pack_field(net, cfg)
     out = torch.empty((B, n, 4), dtype=torch.float32, device=points.device)
-    L.check(L.lib().cnerf_field_forward(C.byref(cfg), L.ptr(fvol_cl), L.ptr(packed), L.ptr(_f32(freq)), L.ptr(_f32(phase)),
+    vs = volumes_struct(levels)
+    L.check(L.lib().cnerf_field_forward(C.byref(cfg), C.byref(vs), L.ptr(packed), L.ptr(_f32(freq)), L.ptr(_f32(phase)),
                                         L.ptr(points), n, L.ptr(out), _stream()), "cnerf_field_forward")
     return out
 
@@ -176,9 +209,10 @@ def render_forward(net, fvol, freq, phase, cam2world, img_size, fov, ray_start, 
     P = R * R
     n = 2 * S if hierarchical else S
     dev = cam2world.device
-    fvol_cl = _f32(fvol) if fvol_is_channel_last else channel_last(fvol)
-    cfg = make_cfg(net, B, fvol_cl.shape[1], R, S, fov, ray_start, ray_end, noise_std, hierarchical, white_back,
+    levels = [_f32(v) for v in as_levels(fvol)] if fvol_is_channel_last else channel_last_levels(fvol)
+    cfg = make_cfg(net, B, levels, R, S, fov, ray_start, ray_end, noise_std, hierarchical, white_back,
                    last_back, clamp_mode)
+    vs = volumes_struct(levels)
     packed = pack_field(net, cfg)
     _, _, ws_bytes = sizes(cfg)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
@@ -203,7 +237,7 @@ def render_forward(net, fvol, freq, phase, cam2world, img_size, fov, ray_start, 
         aux_s = aux_s if aux_s is not None else L.Aux()
         for i, ev in enumerate(field_events):
             aux_s.field_events[i] = ev
-    L.check(L.lib().cnerf_render_forward(C.byref(cfg), L.ptr(fvol_cl), L.ptr(packed), L.ptr(_f32(freq)), L.ptr(_f32(phase)),
+    L.check(L.lib().cnerf_render_forward(C.byref(cfg), C.byref(vs), L.ptr(packed), L.ptr(_f32(freq)), L.ptr(_f32(phase)),
                                          L.ptr(cam2world), C.byref(r), L.ptr(pixels), L.ptr(depth),
                                          C.byref(aux_s) if aux_s is not None else None, L.ptr(ws), _stream()),
             "cnerf_render_forward")
@@ -243,15 +277,17 @@ def pack_field_transposed(net, cfg):
 ACT_BUDGET_BYTES = 48 << 30     # activation / gradient chunk buffers of the backward (288 GB HBM per GPU)
 
 
-def render_backward(net, o, fvol_cl, freq, phase, cam2world, rng, saved, grad_pixels, grad_depth):
-    """Gradients of one render w.r.t. (feature volume (B,C,V,V,V), freq, phase, [field parameters])."""
+def render_backward(net, o, levels, freq, phase, cam2world, rng, saved, grad_pixels, grad_depth):
+    """Gradients of one render w.r.t. (channel-last feature volumes, freq, phase, [field parameters])."""
     B, R, S, hier = o["B"], o["R"], o["S"], o["hier"]
     dev = cam2world.device
-    cfg = make_cfg(net, B, fvol_cl.shape[1], R, S, o["fov"], o["ray_start"], o["ray_end"], o["noise_std"], hier,
+    cfg = make_cfg(net, B, levels, R, S, o["fov"], o["ray_start"], o["ray_end"], o["noise_std"], hier,
                    o["white_back"], o["last_back"], o["clamp_mode"])
+    vs = volumes_struct(levels)
     packed = pack_field(net, cfg)
     packed_t = pack_field_transposed(net, cfg)
-    H, Cin = int(net.hidden_dim), int(net.input_dim)
+    H, k0 = int(net.hidden_dim), int(net.input_dim)
+    n_in = cfg.C // 32 + (1 if net.spec.input == "feat_xyz" else 0)
     kinds = net.spec.layers
     nl = len(kinds)
     npi = R * R * S
@@ -279,9 +315,10 @@ def render_backward(net, o, fvol_cl, freq, phase, cam2world, rng, saved, grad_pi
     n_film = sum(1 for k in kinds if k == "film")
     g_freq = torch.zeros((B, n_film * H), dtype=torch.float32, device=dev) if n_film else None
     g_phase = torch.zeros_like(g_freq) if n_film else None
-    grad_fvol_cl = torch.zeros_like(fvol_cl)
+    grad_levels = [torch.zeros_like(v) for v in levels]
+    gvs = volumes_struct(grad_levels)
 
-    per_image = npi * (32 + 3 * nl * H + 4) * 4
+    per_image = npi * (32 * n_in + 3 * nl * H + 4) * 4
     nb = max(1, min(B, ACT_BUDGET_BYTES // per_image))
     act = None
     u_strat, fine_z_used = _f32(rng.get("u_strat")), f_z
@@ -291,23 +328,25 @@ def render_backward(net, o, fvol_cl, freq, phase, cam2world, rng, saved, grad_pi
             cnt = min(nb, B - b0)
             n = cnt * npi
             if act is None or act[0].shape[0] != n:
-                act = (torch.empty((n, 32), dtype=torch.float32, device=dev),
+                act = (torch.empty((n, 32 * n_in), dtype=torch.float32, device=dev),
                        torch.empty((nl, n, H), dtype=torch.float32, device=dev),
                        torch.empty((nl, n, H), dtype=torch.float32, device=dev),
                        torch.empty((nl, n, H), dtype=torch.float32, device=dev),
                        torch.empty((n, 4), dtype=torch.float32, device=dev))
             a_feat, a_h, a_c, a_g, a_go = act
-            L.check(L.lib().cnerf_field_backward(C.byref(cfg), pss, b0, cnt, L.ptr(fvol_cl), L.ptr(packed), L.ptr(packed_t),
+            L.check(L.lib().cnerf_field_backward(C.byref(cfg), pss, b0, cnt, C.byref(vs), L.ptr(packed), L.ptr(packed_t),
                                                  L.ptr(freq), L.ptr(phase), L.ptr(cam2world), L.ptr(u_strat),
                                                  L.ptr(fine_z_used) if hier else None, L.ptr(g_out), L.ptr(saved_out),
                                                  L.ptr(a_feat), L.ptr(a_h), L.ptr(a_c), L.ptr(a_g), L.ptr(a_go),
-                                                 L.ptr(grad_fvol_cl), _stream()), "cnerf_field_backward")
+                                                 C.byref(gvs), _stream()), "cnerf_field_backward")
             # parameter gradients: plain GEMMs and column sums over the chunk matrices (rocBLAS through torch)
             fidx = 0
             for l, kind in enumerate(kinds):
                 X = (a_feat if l == 0 else a_h[l - 1]).view(cnt, npi, -1)
                 G = a_g[l].view(cnt, npi, H)
                 dWarg = torch.bmm(G.transpose(1, 2), X)          # (cnt, H, K) per image
+                if l == 0:
+                    dWarg = dWarg[..., :k0]                      # drop the zero padding of the last input tile
                 cs = G.sum(1)                                    # (cnt, H)
                 if kind == "film":
                     sl = slice(fidx * H, (fidx + 1) * H)
@@ -326,51 +365,53 @@ def render_backward(net, o, fvol_cl, freq, phase, cam2world, rng, saved, grad_pi
     for l in range(nl):
         grads += [dW[l], db[l]]
     grads += [dW_head, db_head]
-    return grad_fvol_cl, g_freq, g_phase, grads
+    return grad_levels, g_freq, g_phase, grads
 
 
 class RenderFunction(torch.autograd.Function):
-    """ImplicitGenerator3d.forward as one autograd node: differentiable w.r.t. the feature volume, freq/phase (and through
-    them the mapping network and the global feature) and the field parameters; not w.r.t. cameras or sample positions
-    (the reference runs those under no_grad: generators.py:57,111)."""
+    """ImplicitGenerator3d.forward as one autograd node: differentiable w.r.t. the feature volume(s), freq/phase (and
+    through them the mapping network and the global feature) and the field parameters; not w.r.t. cameras or sample
+    positions (the reference runs those under no_grad: generators.py:57,111)."""
 
     @staticmethod
-    def forward(ctx, net, o, rng, fvol, freq, phase, cam2world, *params):
-        fvol_cl = channel_last(fvol.detach())
+    def forward(ctx, net, o, rng, cam2world, freq, phase, n_vols, *rest):
+        vols, params = rest[:n_vols], rest[n_vols:]
+        levels = [channel_last(v.detach()) for v in vols]
         fr = freq.detach() if freq is not None else None
         ph = phase.detach() if phase is not None else None
         need_grad = any(ctx.needs_input_grad)   # (grad mode is always off inside Function.forward)
-        pixels, depth, aux = render_forward(net, fvol_cl, fr, ph, cam2world, o["R"], o["fov"], o["ray_start"], o["ray_end"],
+        pixels, depth, aux = render_forward(net, levels, fr, ph, cam2world, o["R"], o["fov"], o["ray_start"], o["ray_end"],
                                             o["S"], o["hier"], o["clamp_mode"], o["noise_std"], o["white_back"],
                                             o["last_back"], rng, want_aux=o["want_aux"], fvol_is_channel_last=True,
                                             field_events=o.get("field_events"),
                                             aux_keys=SAVED_KEYS if need_grad and not o["want_aux"] else None)
-        ctx.net, ctx.o, ctx.rng = net, o, rng
-        ctx.aux = aux
+        ctx.net, ctx.o, ctx.rng, ctx.n_vols = net, o, rng, n_vols
         if need_grad:
             saved = [aux.get(k) for k in SAVED_KEYS]
             if o["hier"] and rng.get("fine_z") is not None:
                 saved[3] = _f32(rng["fine_z"]).reshape(saved[1].shape)   # teacher-forced depths are what the fine pass used
-            ctx.saved = (fvol_cl, fr, ph, _f32(cam2world), tuple(saved))
+            ctx.saved = (levels, fr, ph, _f32(cam2world), tuple(saved))
         RenderFunction.last_aux = aux
         return pixels, depth
 
     @staticmethod
     def backward(ctx, grad_pixels, grad_depth):
-        fvol_cl, fr, ph, cam2world, saved = ctx.saved
-        g_fvol_cl, g_freq, g_phase, g_params = render_backward(ctx.net, ctx.o, fvol_cl, fr, ph, cam2world, ctx.rng, saved,
-                                                               grad_pixels.contiguous(),
-                                                               grad_depth.contiguous() if grad_depth is not None else None)
-        return (None, None, None, channel_first(g_fvol_cl), g_freq, g_phase, None, *g_params)
+        levels, fr, ph, cam2world, saved = ctx.saved
+        g_levels, g_freq, g_phase, g_params = render_backward(ctx.net, ctx.o, levels, fr, ph, cam2world, ctx.rng, saved,
+                                                              grad_pixels.contiguous(),
+                                                              grad_depth.contiguous() if grad_depth is not None else None)
+        return (None, None, None, None, g_freq, g_phase, None, *[channel_first(g) for g in g_levels], *g_params)
 
 
 def render(net, fvol, freq, phase, cam2world, img_size, fov, ray_start, ray_end, num_steps, hierarchical, clamp_mode,
            noise_std, white_back=False, last_back=False, rng=None, want_aux=False, field_events=None):
-    """Differentiable entry used by ImplicitGenerator3d.forward.  Returns (pixels, depth, aux dict)."""
+    """Differentiable entry used by ImplicitGenerator3d.forward.  fvol: (B,C,V,V,V) or a list of pyramid levels.
+    Returns (pixels, depth, aux dict)."""
     o = dict(B=cam2world.shape[0], R=int(img_size), S=int(num_steps), fov=float(fov), ray_start=float(ray_start),
              ray_end=float(ray_end), hier=bool(hierarchical), clamp_mode=clamp_mode, noise_std=float(noise_std),
              white_back=bool(white_back), last_back=bool(last_back), want_aux=bool(want_aux), field_events=field_events)
     if clamp_mode not in ("relu", "softplus"):
         raise TypeError("Need to choose clamp mode")
-    pixels, depth = RenderFunction.apply(net, o, rng or {}, fvol, freq, phase, cam2world, *net.field_params())
+    vols = as_levels(fvol)
+    pixels, depth = RenderFunction.apply(net, o, rng or {}, cam2world, freq, phase, len(vols), *vols, *net.field_params())
     return pixels, depth, (RenderFunction.last_aux if want_aux else {})

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define CNERF_ABI_VERSION 1
+#define CNERF_ABI_VERSION 2
 
 #define CNERF_OK 0
 #define CNERF_EINVAL (-22)  /* bad argument / unsupported shape (message via cnerf_last_error) */
@@ -30,6 +30,7 @@ extern "C" {
 #define CNERF_ELAUNCH (-5)  /* the HIP runtime refused a launch */
 
 #define CNERF_MAX_LAYERS 16
+#define CNERF_MAX_LEVELS 4  /* feature-pyramid levels (siren.py:1444-1473) */
 
 /* cnerf_cfg.flags */
 #define CNERF_F_HIERARCHICAL (1u << 0) /* generators.py:110  coarse pass + importance resampling + fine pass */
@@ -37,6 +38,7 @@ extern "C" {
 #define CNERF_F_LAST_BACK (1u << 2)    /* volumetric_rendering.py:53  w[last] += 1 - sum(w) */
 #define CNERF_F_SOFTPLUS (1u << 3)     /* clamp_mode == "softplus" (else "relu"), volumetric_rendering.py:41-44 */
 #define CNERF_F_SIGMOID_RGB (1u << 4)  /* siren.py:1227-1234  sigmoid on channels 0..2 of the head */
+#define CNERF_F_INPUT_XYZ (1u << 5)    /* siren.py:1158  layer 0 sees features || world xyz (TALLSIREN_dgx) */
 
 /* layer kinds of the field network (siren.py:146-230) */
 #define CNERF_LAYER_FILM 0 /* y = sin(freq * (W x + b) + phase), freq/phase per image */
@@ -47,8 +49,8 @@ typedef struct cnerf_cfg {
     int32_t B;            /* images in this call */
     int32_t R;            /* img_size */
     int32_t S;            /* num_steps (coarse samples per ray) */
-    int32_t V;            /* feature volume side */
-    int32_t C;            /* feature channels = input width of layer 0 (32) */
+    int32_t V;            /* feature volume side (level 0) */
+    int32_t C;            /* feature channels over all levels; input width of layer 0 = C (+3 with CNERF_F_INPUT_XYZ) */
     int32_t H;            /* hidden width (multiple of 32, <= 256) */
     int32_t L;            /* number of entries in layer_kind */
     int32_t layer_kind[CNERF_MAX_LAYERS];
@@ -59,7 +61,19 @@ typedef struct cnerf_cfg {
     uint32_t flags;       /* CNERF_F_* */
     double fov_deg;       /* forward(fov), degrees; kept in double because the reference takes tan() of the
                              Python float before rounding the focal length to fp32 (volumetric_rendering.py:85-87) */
+    int32_t n_levels;     /* feature volumes looked up and concatenated (0 or 1: the single volume V, C) */
+    int32_t level_V[CNERF_MAX_LEVELS]; /* side of level i */
+    int32_t level_C[CNERF_MAX_LEVELS]; /* channels of level i (multiple of 32); sum = C */
 } cnerf_cfg;
+
+/* Feature volumes, channel-last: level[i] is (B, V_i, V_i, V_i, C_i).  HOST struct of device pointers.  The gradient
+ * twin of the backward has the same shapes and is accumulated into. */
+typedef struct cnerf_volumes {
+    const float* level[CNERF_MAX_LEVELS];
+} cnerf_volumes;
+typedef struct cnerf_grad_volumes {
+    float* level[CNERF_MAX_LEVELS];
+} cnerf_grad_volumes;
 
 /* Raw parameters of the field network, exactly as the nn.Module holds them (row-major [out][in]).
  * For a RES layer i: w[i]/b[i] = fc1, w2[i]/b2[i] = fc2.  Replaces the state the reference keeps in
@@ -124,7 +138,7 @@ int cnerf_workspace_bytes(const cnerf_cfg* cfg, size_t* packed, size_t* fvol_cl,
 
 /* (B,C,V,V,V) channel-first, as unet3d emits it (generators/unet3d.py) -> (B,V,V,V,C) channel-last, so that one
  * trilinear corner is one contiguous C*4-byte line.  Replaces the layout F.grid_sample reads (siren.py:561-567). */
-int cnerf_fvol_channel_last(int32_t B, int32_t C, int32_t V, const float* fvol_cf, float* fvol_cl, void* stream);
+int cnerf_fvol_channel_last(int32_t B, int32_t C, int32_t V, const float* fvol_cf, float* fvol_cl, void* stream); /* C % 32 == 0 */
 /* Transpose of the above (used for the gradient of the feature volume). */
 int cnerf_fvol_channel_first(int32_t B, int32_t C, int32_t V, const float* fvol_cl, float* fvol_cf, void* stream);
 
@@ -140,7 +154,7 @@ int cnerf_gather_features(const cnerf_cfg* cfg, const float* fvol_cl, const floa
 /* Field network at explicit points: points (B,n,3) -> rgb_sigma (B,n,4).
  * Replaces <SIREN>.forward(points, z, img_size, num_steps) (siren.py:637-668 and siblings; extract_shapes.py:63-69).
  * freq/phase: (B, n_film*H) with freq already *15+30 (siren.py:650), NULL when the network has no FiLM layer. */
-int cnerf_field_forward(const cnerf_cfg* cfg, const float* fvol_cl, const float* packed, const float* freq,
+int cnerf_field_forward(const cnerf_cfg* cfg, const cnerf_volumes* vols, const float* packed, const float* freq,
                         const float* phase, const float* points, int64_t n_per_image, float* rgb_sigma, void* stream);
 
 /* Alpha compositing of n samples per ray: rgb_sigma (rays,n,4), z (rays,n), eps (rays,n) or NULL ->
@@ -156,7 +170,7 @@ int cnerf_resample(int64_t rays, int32_t S, const float* z, const float* weights
 
 /* The whole path: ImplicitGenerator3d.forward (generators.py:33-187).
  *   cam2world (B,4,4) row-major;  pixels (B,3,R,R) = 2*rgb-1;  depth (B,R,R).  aux may be NULL. */
-int cnerf_render_forward(const cnerf_cfg* cfg, const float* fvol_cl, const float* packed, const float* freq,
+int cnerf_render_forward(const cnerf_cfg* cfg, const cnerf_volumes* vols, const float* packed, const float* freq,
                          const float* phase, const float* cam2world, const cnerf_rng* rng, float* pixels,
                          float* depth, const cnerf_aux* aux, void* workspace, void* stream);
 
@@ -167,7 +181,7 @@ int cnerf_render_forward(const cnerf_cfg* cfg, const float* fvol_cl, const float
  * Step 2  cnerf_field_backward per pass (coarse, fine) and per chunk of images: re-runs the field forward storing the
  *         activations, back-propagates through the MLP on the MFMA units, scatter-adds d(feature volume) with fp32
  *         atomics, and leaves row-major activation / gradient matrices in the caller's chunk buffers:
- *             act_feat (n,32)   x0 = looked-up features            act_go (n,4)   d/d head pre-activation
+ *             act_feat (n,32k)  x0 = layer-0 input tiles            act_go (n,4)   d/d head pre-activation
  *             act_h (L,n,H)     x_l = sin(arg_l)                    act_g  (L,n,H) d/d arg_l
  *             act_c (L,n,H)     cos(arg_l)                          (n = images_in_chunk * points_per_image)
  *         The parameter gradients are then plain GEMMs / column sums over these matrices (rocBLAS territory):
@@ -190,13 +204,14 @@ int cnerf_merge_composite_backward(const cnerf_cfg* cfg, const float* coarse_rgb
 /* pass: 0 = coarse samples (needs u_strat as in the forward), 1 = fine samples (needs fine_z), 2 = explicit points:
  * the u_strat argument then carries points (B, R*R*S, 3) (backward of cnerf_field_forward).  Images [image0,
  * image0 + n_images) of the call described by cfg.  All per-image inputs are the FULL tensors of the forward (the
- * function offsets them); grad_rgb_sigma / saved_rgb_sigma are the (B,P,S,4) tensors of that pass; grad_fvol_cl is the
- * full (B,V,V,V,32) gradient volume, accumulated into (zero it first).  act_* are chunk buffers for n_images images. */
-int cnerf_field_backward(const cnerf_cfg* cfg, int32_t pass, int32_t image0, int32_t n_images, const float* fvol_cl,
+ * function offsets them); grad_rgb_sigma / saved_rgb_sigma are the (B,P,S,4) tensors of that pass; grad_vols are the
+ * full gradient volumes, accumulated into (zero them first).  act_* are chunk buffers for n_images images; act_feat is
+ * (n, 32 * input tiles): the concatenated looked-up features (and xyz, zero padded) that layer 0 saw. */
+int cnerf_field_backward(const cnerf_cfg* cfg, int32_t pass, int32_t image0, int32_t n_images, const cnerf_volumes* vols,
                          const float* packed, const float* packed_t, const float* freq, const float* phase,
                          const float* cam2world, const float* u_strat, const float* fine_z,
                          const float* grad_rgb_sigma, const float* saved_rgb_sigma, float* act_feat, float* act_h,
-                         float* act_c, float* act_g, float* act_go, float* grad_fvol_cl, void* stream);
+                         float* act_c, float* act_g, float* act_go, const cnerf_grad_volumes* grad_vols, void* stream);
 
 #ifdef __cplusplus
 }

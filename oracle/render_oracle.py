@@ -31,11 +31,16 @@ VOXEL_LENGTH = 1.2  # generators/siren.py:555 (hard-coded in every feature-volum
 # layer kinds:  "film"  y = sin(freq * (x W^T + b) + phase), freq/phase per image   (siren.py:146-160)
 #               "sine"  y = sin(x W^T + b)                                           (siren.py:180-199)
 #               "res"   y = sin(x + fc2(sin(fc1 x)))                                 (siren.py:218-230)
+#               "pfilm" y = sin(freq(p) * (x W^T + b) + phase(p)), freq/phase per POINT from a mapping MLP of the
+#                       looked-up feature                                             (siren.py:163-177, 81-101, 232-331)
+# input kinds:  "feat" looked-up feature; "feat_xyz" feature || world xyz (siren.py:1158); "pyramid" features of several
+#               volumes concatenated (siren.py:1444-1473); "xyz" world position only (TALLSIREN, siren.py:312)
 @dataclass(frozen=True)
 class FieldSpec:
     layers: Tuple[str, ...]
     sigmoid_rgb: bool
     has_global: bool
+    input: str = "feat"
 
     @property
     def n_film(self) -> int:
@@ -51,6 +56,9 @@ FIELD_SPECS: Dict[str, FieldSpec] = {
     "SHORTSIREN_FRes": FieldSpec(("sine", "res", "sine"), True, False),          # siren.py:906-979
     "TALLSIREN_dRes": FieldSpec(("sine", "res", "res", "sine"), False, False),   # siren.py:333-408
     "TALLSIREN_dResLong": FieldSpec(("sine", "res", "res", "res", "res", "sine"), False, False),  # :411-488
+    "TALLSIREN_dgx": FieldSpec(("film",) * 8, False, True, "feat_xyz"),                           # :1068-1169
+    "SHORTSIREN_FG_Pyrmd": FieldSpec(("film",) * 4, True, True, "pyramid"),                       # :671-741
+    "TALLSIREN": FieldSpec(("pfilm",) * 8, False, False, "xyz"),                                  # :232-331
 }
 
 
@@ -166,11 +174,20 @@ def film_params(spec: FieldSpec, params: Dict[str, torch.Tensor], global_feature
 
 
 def field_mlp(spec: FieldSpec, params: Dict[str, torch.Tensor], feats: torch.Tensor,
-              global_feature: Optional[torch.Tensor]) -> torch.Tensor:
-    """feats (B,N,C) -> rgb_sigma (B,N,4)."""
+              global_feature: Optional[torch.Tensor], points: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """feats (B,N,C) -> rgb_sigma (B,N,4).  points (B,N,3) is needed by the input kinds that see the position."""
     H = params["final_layer.weight"].shape[1]
     freq, phase = film_params(spec, params, global_feature, H)
     x = feats
+    if spec.input == "feat_xyz":
+        x = torch.cat([feats, points], -1)
+    elif spec.input == "xyz":
+        # per-point FiLM parameters from the looked-up feature: Linear -> LeakyReLU(0.2) -> Linear (siren.py:81-101)
+        mh = F.leaky_relu(F.linear(feats, params["mapping_network.network.0.weight"], params["mapping_network.network.0.bias"]), 0.2)
+        fo = F.linear(mh, params["mapping_network.network.2.weight"], params["mapping_network.network.2.bias"])
+        half = fo.shape[-1] // 2
+        pfreq, pphase = fo[..., :half] * 15 + 30, fo[..., half:]
+        x = points
     f = 0
     for i, kind in enumerate(spec.layers):
         pre = f"network.{i}."
@@ -180,6 +197,9 @@ def field_mlp(spec: FieldSpec, params: Dict[str, torch.Tensor], feats: torch.Ten
             ph = phase[:, f * H:(f + 1) * H].unsqueeze(1)
             x = torch.sin(fr * x + ph)
             f += 1
+        elif kind == "pfilm":
+            x = F.linear(x, params[pre + "layer.weight"], params[pre + "layer.bias"])
+            x = torch.sin(pfreq[..., i * H:(i + 1) * H] * x + pphase[..., i * H:(i + 1) * H])
         elif kind == "sine":
             x = torch.sin(F.linear(x, params[pre + "layer.weight"], params[pre + "layer.bias"]))
         elif kind == "res":
@@ -195,9 +215,13 @@ def field_mlp(spec: FieldSpec, params: Dict[str, torch.Tensor], feats: torch.Ten
 
 
 def field_eval(spec: FieldSpec, params, fvol_cf, global_feature, points, explicit_lookup=False):
+    """fvol_cf: one (B,C,V,V,V) volume, or a list of them for the "pyramid" input kind."""
     look = trilinear_lookup_explicit if explicit_lookup else trilinear_lookup
-    feats = look(fvol_cf, points)
-    return field_mlp(spec, params, feats, global_feature), feats
+    if isinstance(fvol_cf, (list, tuple)):
+        feats = torch.cat([look(v, points) for v in fvol_cf], -1)
+    else:
+        feats = look(fvol_cf, points)
+    return field_mlp(spec, params, feats, global_feature, points), feats
 
 
 # ---------------------------------------------------------------------------------------

@@ -74,6 +74,18 @@ FIXTURES = {
     "short_fg_s40": dict(variant="SHORTSIREN_FG", B=1, R=8, S=40, V=12, C=32, H=64, Z=48,
                          noise=0.0, clamp="relu", white_back=True, last_back=False, seed=10, full=True,
                          grads=True),
+    # feature || xyz input (K0 = 35)
+    "tall_dgx_small": dict(variant="TALLSIREN_dgx", B=1, R=16, S=8, V=10, C=32, H=64, Z=48,
+                           noise=0.0, clamp="relu", white_back=True, last_back=False, seed=11, full=True,
+                           grads=True, input_dim=35),
+    # feature pyramid: three volumes of different resolution / width concatenated (K0 = 128)
+    "short_pyrmd_small": dict(variant="SHORTSIREN_FG_Pyrmd", B=2, R=12, S=12, V=12, C=32, H=64, Z=48,
+                              noise=0.0, clamp="relu", white_back=True, last_back=False, seed=12, full=True,
+                              grads=True, input_dim=128, pyramid=[(32, 12), (64, 6), (32, 3)]),
+    # per-point FiLM from the looked-up feature, xyz input (pi-GAN style TALLSIREN)
+    "tallsiren_small": dict(variant="TALLSIREN", B=1, R=12, S=8, V=10, C=32, H=64, Z=32,
+                            noise=0.0, clamp="relu", white_back=True, last_back=False, seed=13, full=True,
+                            grads=True),
 }
 
 # variants whose `z` is the bare feature volume (no global feature)
@@ -94,10 +106,12 @@ def build(name):
     variant = spec["variant"]
     # FG family: FiLMLayer(input_dim, hidden) eats the looked-up feature -> input_dim = C,
     # z_dim = width of the global feature.  Plain-sine families set input_dim = z_dim themselves.
-    if variant in NO_GLOBAL:
+    if variant == "TALLSIREN":      # input = xyz; z_dim = width of the looked-up feature feeding the per-point mapping net
+        gen = ref_gen.ImplicitGenerator3d(variant, z_dim=C, input_dim=3, output_dim=4, hidden_dim=H)
+    elif variant in NO_GLOBAL:
         gen = ref_gen.ImplicitGenerator3d(variant, z_dim=C, input_dim=C, output_dim=4, hidden_dim=H)
     else:
-        gen = ref_gen.ImplicitGenerator3d(variant, z_dim=Z, input_dim=C, output_dim=4, hidden_dim=H)
+        gen = ref_gen.ImplicitGenerator3d(variant, z_dim=Z, input_dim=spec.get("input_dim", C), output_dim=4, hidden_dim=H)
     gen.set_device(torch.device("cpu"))
     gen.eval()
     # Default init gives near-zero densities (an all-background image pins nothing): scale the head so
@@ -109,6 +123,9 @@ def build(name):
         gen.siren.final_layer.bias[3] += 0.25
 
     fvol = (torch.randn(B, C, V, V, V) * 0.5).requires_grad_(True)
+    pyr = None
+    if "pyramid" in spec:
+        pyr = [fvol] + [(torch.randn(B, c, v, v, v) * 0.5).requires_grad_(True) for c, v in spec["pyramid"][1:]]
     glob = torch.randn(B, Z).requires_grad_(True)
     origins = ref_vr.sample_camera_positions(torch.device("cpu"), "y", cam_r_start=0.7, cam_r_end=1.5, n=B)
     cam2world = ref_vr.create_cam2world_matrix(origins, "y", device=torch.device("cpu")).float()
@@ -150,7 +167,7 @@ def build(name):
     torch.rand, torch.randn, F.grid_sample, torch.searchsorted, torch.sort = w_rand, w_randn, w_gs, w_ss, w_sort
     ref_gen.fancy_integration, ref_gen.sample_pdf = w_fi, w_sp
     try:
-        z = fvol if variant in NO_GLOBAL else (fvol, glob)
+        z = fvol if variant in NO_GLOBAL else ((pyr if pyr is not None else fvol), glob)
         kw = dict(clamp_mode=spec["clamp"], nerf_noise=spec["noise"], white_back=spec["white_back"],
                   last_back=spec["last_back"],
                   # the caller splats its whole metadata dict: extra keys must be ignored
@@ -167,6 +184,9 @@ def build(name):
                 hierarchical=hier, has_global=variant not in NO_GLOBAL)
     out["meta_json"] = np.frombuffer(__import__("json").dumps(meta).encode(), dtype=np.uint8)
     out["feature_volume"] = fvol.detach().numpy()
+    if pyr is not None:
+        for i, v in enumerate(pyr[1:], 1):
+            out[f"feature_volume_l{i}"] = v.detach().numpy()
     if variant not in NO_GLOBAL:
         out["global_feature"] = glob.detach().numpy()
     out["cam2worlds"] = cam2world.numpy()
@@ -198,7 +218,9 @@ def build(name):
         out["coarse_weights"] = rec["weights"][0].numpy().reshape(B, R * R, S)
     if spec["full"]:
         out["coarse_points"] = rec["siren_in"][0].numpy().reshape(B, R * R, S, 3)
-        out["coarse_feat"] = rec["feat"][0].numpy().reshape(B, C, R * R * S).transpose(0, 2, 1).copy()
+        nlev = len(pyr) if pyr is not None else 1     # grid_sample runs once per pyramid level and pass
+        out["coarse_feat"] = np.concatenate([rec["feat"][i].numpy().reshape(B, -1, R * R * S).transpose(0, 2, 1)
+                                             for i in range(nlev)], -1).copy()
         out["final_weights"] = rec["weights"][-1].numpy().reshape(B, R * R, -1)
         if hier:
             out["cdf"] = rec["cdf"][0].numpy().reshape(B, R * R, S - 1)
@@ -207,13 +229,18 @@ def build(name):
     if spec["grads"]:
         loss = pixels.square().mean() + depth.mean()
         params = dict(gen.named_parameters())
-        leaves = list(params.values()) + [fvol] + ([] if variant in NO_GLOBAL else [glob])
+        extra = pyr[1:] if pyr is not None else []
+        leaves = list(params.values()) + [fvol] + ([] if variant in NO_GLOBAL else [glob]) + extra
         grads = torch.autograd.grad(loss, leaves, allow_unused=True)
         for (k, _), g in zip(params.items(), grads):
             out["grad/" + k] = (g if g is not None else torch.zeros_like(params[k])).numpy()
         out["grad_feature_volume"] = grads[len(params)].numpy()
+        nxt = len(params) + 1
         if variant not in NO_GLOBAL:
-            out["grad_global_feature"] = grads[len(params) + 1].numpy()
+            out["grad_global_feature"] = grads[nxt].numpy()
+            nxt += 1
+        for i, g in enumerate(grads[nxt:], 1):
+            out[f"grad_feature_volume_l{i}"] = g.numpy()
         out["loss"] = np.float32(loss.item())
 
     path = os.path.join(HERE, name + ".npz")

@@ -22,7 +22,7 @@ def test_build_and_exports():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/cnerf.h but not exported"
     assert declared == set(cnerf_amd._lib.PROTOTYPES), "ctypes prototypes out of sync with the header"
-    assert lib.cnerf_abi_version() == 1
+    assert lib.cnerf_abi_version() == cnerf_amd._lib.ABI_VERSION
 
 
 def test_cfg_validation_without_gpu():
@@ -55,8 +55,10 @@ def test_init_and_state_dict_match_reference(golden, name):
     g = golden(name)
     m = g.meta
     torch.manual_seed(m["seed"])
-    if m["has_global"]:
-        gen = ImplicitGenerator3d(m["variant"], z_dim=m["Z"], input_dim=m["C"], output_dim=4, hidden_dim=m["H"])
+    if m["variant"] == "TALLSIREN":
+        gen = ImplicitGenerator3d(m["variant"], z_dim=m["C"], input_dim=3, output_dim=4, hidden_dim=m["H"])
+    elif m["has_global"]:
+        gen = ImplicitGenerator3d(m["variant"], z_dim=m["Z"], input_dim=m.get("input_dim", m["C"]), output_dim=4, hidden_dim=m["H"])
     else:
         gen = ImplicitGenerator3d(m["variant"], z_dim=m["C"], input_dim=m["C"], output_dim=4, hidden_dim=m["H"])
     sd = gen.state_dict()

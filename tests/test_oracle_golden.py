@@ -20,7 +20,9 @@ def T(x):
 def run_oracle(g, explicit=False):
     m = g.meta
     params = {k: T(v) for k, v in g.params().items()}
-    return O.render(m["variant"], params, T(g["feature_volume"]), T(g.get("global_feature")), T(g["cam2worlds"]),
+    vols = g.volumes()
+    vols = [T(v) for v in vols] if isinstance(vols, list) else T(vols)
+    return O.render(m["variant"], params, vols, T(g.get("global_feature")), T(g["cam2worlds"]),
                     m["R"], m["fov"], m["ray_start"], m["ray_end"], m["S"], m["hierarchical"], m["clamp"], m["noise"],
                     m["white_back"], m["last_back"], T(g["u_strat"]), T(g.get("eps_coarse")), T(g.get("u_fine")),
                     T(g.get("eps_final")), explicit_lookup=explicit)
@@ -60,7 +62,7 @@ def test_explicit_trilinear_is_the_aten_op(golden, name):
     a = O.trilinear_lookup(T(g["feature_volume"]), pts)
     b = O.trilinear_lookup_explicit(T(g["feature_volume"]), pts)
     assert torch.equal(a, b)
-    assert scaled_err(b, g["coarse_feat"]) < 1e-6
+    assert scaled_err(b, g["coarse_feat"][..., :32]) < 1e-6
 
 
 def test_ray_convention():
