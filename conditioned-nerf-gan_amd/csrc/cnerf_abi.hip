@@ -357,7 +357,7 @@ int cnerf_backward_bytes(const cnerf_cfg* cfg, size_t* packed_t) {
     if (int rc = check_cfg(cfg, false)) return rc;
     const size_t NT = cfg->H / 32, tile = 4 * 64 * 4;
     size_t fl = NT * 2 * 64;                                  // head^T
-    for (int l = cfg->L - 1; l >= 1; --l) fl += NT * NT * tile;
+    for (int l = cfg->L - 1; l >= 1; --l) fl += (cfg->layer_kind[l] == CNERF_LAYER_RES ? 2 : 1) * NT * NT * tile;
     fl += (size_t)packed_layout(cfg).n_in * NT * tile;       // layer 0 transposed: one 32-row output tile per input tile
     if (packed_t) *packed_t = align256(fl * sizeof(float));
     return CNERF_OK;
@@ -367,8 +367,6 @@ int cnerf_pack_field_transposed(const cnerf_cfg* cfg, const cnerf_field_params* 
     g_err[0] = 0;
     if (int rc = check_cfg(cfg, false)) return rc;
     if (!p || !packed_t) return fail(CNERF_EINVAL, "pack_field_transposed: NULL argument");
-    for (int l = 0; l < cfg->L; ++l)
-        if (cfg->layer_kind[l] == CNERF_LAYER_RES) return fail(CNERF_ENOSYS, "backward through residual blocks is not implemented");
     hipStream_t stream = (hipStream_t)stream_;
     const int H = cfg->H, NT = H / 32;
     const size_t tile = 4 * 64 * 4;
@@ -376,8 +374,13 @@ int cnerf_pack_field_transposed(const cnerf_cfg* cfg, const cnerf_field_params* 
     if (!p->w_final) return fail(CNERF_EINVAL, "pack_field_transposed: head is NULL");
     if (hipError_t e = launch_pack_head_t(p->w_final, H, dst, stream)) return hip_fail(e, "pack_head_t");
     dst += (size_t)NT * 2 * 64;
-    for (int l = cfg->L - 1; l >= 1; --l) {
+    for (int l = cfg->L - 1; l >= 1; --l) {      // in the order the backward consumes them (a residual block: fc2 then fc1)
         if (!p->w[l]) return fail(CNERF_EINVAL, "pack_field_transposed: layer %d weight is NULL", l);
+        if (cfg->layer_kind[l] == CNERF_LAYER_RES) {
+            if (!p->w2[l]) return fail(CNERF_EINVAL, "pack_field_transposed: residual layer %d fc2 is NULL", l);
+            if (hipError_t e = launch_pack_matrix_t(p->w2[l], H, H, NT, dst, stream)) return hip_fail(e, "pack_matrix_t");
+            dst += (size_t)NT * NT * tile;
+        }
         if (hipError_t e = launch_pack_matrix_t(p->w[l], H, H, NT, dst, stream)) return hip_fail(e, "pack_matrix_t");
         dst += (size_t)NT * NT * tile;
     }
@@ -410,8 +413,6 @@ int cnerf_field_backward(const cnerf_cfg* cfg, int32_t pass, int32_t image0, int
                          float* act_c, float* act_g, float* act_go, const cnerf_grad_volumes* grad_vols, void* stream_) {
     g_err[0] = 0;
     if (int rc = check_cfg(cfg, true)) return rc;
-    for (int l = 0; l < cfg->L; ++l)
-        if (cfg->layer_kind[l] == CNERF_LAYER_RES) return fail(CNERF_ENOSYS, "backward through residual blocks is not implemented");
     if (image0 < 0 || n_images < 1 || image0 + n_images > cfg->B) return fail(CNERF_EINVAL, "field_backward: image range out of [0,B)");
     if (pass < 0 || pass > 2) return fail(CNERF_EINVAL, "field_backward: pass must be 0 (coarse), 1 (fine) or 2 (explicit points)");
     if (!vols || !packed || !packed_t || !cam2world || !grad_rgb_sigma || !saved_rgb_sigma || !act_feat || !act_h || !act_c ||

@@ -407,10 +407,18 @@ __global__ __launch_bounds__(256) void field_tile_kernel(FieldArgs a) {
                 STAMP(3);   // hidden layers
             } else {
                 // y = sin(W1 x + b1);  x = sin(x + W2 y + b2)   (tile t of x is dead once its own residual is added)
-                mlp_matrix<NT, NT, EPI_FILM, false>(wp, bias, ones, zeros, x.v, nullptr, y.v, lane, h, nullptr, nullptr);
+                mlp_matrix<NT, NT, EPI_FILM, STORE>(wp, bias, ones, zeros, x.v, nullptr, y.v, lane, h, row_h, row_c);
+                if (STORE) {
+                    row_h += act_layer;
+                    row_c += act_layer;
+                }
                 wp += (size_t)NT * NT * TILE4;
                 bias += H;
-                mlp_matrix<NT, NT, EPI_FILM_RES, false>(wp, bias, ones, zeros, y.v, x.v, x.v, lane, h, nullptr, nullptr);
+                mlp_matrix<NT, NT, EPI_FILM_RES, STORE>(wp, bias, ones, zeros, y.v, x.v, x.v, lane, h, row_h, row_c);
+                if (STORE) {
+                    row_h += act_layer;
+                    row_c += act_layer;
+                }
                 wp += (size_t)NT * NT * TILE4;
                 bias += H;
             }
@@ -529,7 +537,7 @@ __device__ __forceinline__ void bwd_activation(f32x16* g, const float* __restric
     }
 }
 
-template <int NT>
+template <int NT, bool HAS_RES>
 __global__ __launch_bounds__(256) void field_backward_kernel(FieldArgs a) {
     __shared__ float s_g[4][32][33];     // per wave: g_feat [point][channel] (padded)
     __shared__ int s_base[4][32][8];
@@ -577,13 +585,40 @@ __global__ __launch_bounds__(256) void field_backward_kernel(FieldArgs a) {
         }
         const f32x4* wp = reinterpret_cast<const f32x4*>(wt);
         const float* ones = a.bias + a.bias_floats;
-        int film_idx = 0;
-        for (int l = 0; l < a.L; ++l) film_idx += (a.layer_kind[l] == CNERF_LAYER_FILM);
+        int film_idx = 0, sub = -1;       // sub: index of the activation slab (a residual block owns two)
+        for (int l = 0; l < a.L; ++l) {
+            film_idx += (a.layer_kind[l] == CNERF_LAYER_FILM);
+            sub += (a.layer_kind[l] == CNERF_LAYER_RES) ? 2 : 1;
+        }
         for (int l = a.L - 1; l >= 0; --l) {
-            const bool film = a.layer_kind[l] == CNERF_LAYER_FILM;
+            const int kind = a.layer_kind[l];
+            if (HAS_RES && kind == CNERF_LAYER_RES) {
+                // y = sin(W1 x + b1) [slab sub-1];  x' = sin(x + W2 y + b2) [slab sub]
+                float* row_gb = a.act_g + (size_t)sub * act_layer + gpt * H;
+                bwd_activation<NT>(g.v, a.act_c + (size_t)sub * act_layer + gpt * H, row_gb, ones, h);        // g = g_arg_b
+                bwd_matrix<NT, NT>(wp, g.v, g2.v, lane);                                                       // g2 = W2^T g_arg_b
+                wp += (size_t)NT * NT * TILE4;
+                bwd_activation<NT>(g2.v, a.act_c + (size_t)(sub - 1) * act_layer + gpt * H,
+                                   a.act_g + (size_t)(sub - 1) * act_layer + gpt * H, ones, h);                // g2 = g_arg_a
+                bwd_matrix<NT, NT>(wp, g2.v, g.v, lane);                                                       // g = W1^T g_arg_a
+                wp += (size_t)NT * NT * TILE4;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {       // + the identity path: g_arg_b, re-read from the rows this lane just wrote
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        const f32x4 q = *reinterpret_cast<const volatile f32x4*>(row_gb + 32 * t + 8 * gq + 4 * h);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) g.v[t][4 * gq + e] = g.v[t][4 * gq + e] + q[e];
+                    }
+                }
+                sub -= 2;
+                continue;
+            }
+            const bool film = kind == CNERF_LAYER_FILM;
             if (film) --film_idx;
             const float* fr = film ? a.freq + (size_t)b * a.film_stride + (size_t)film_idx * H : ones;
-            bwd_activation<NT>(g.v, a.act_c + (size_t)l * act_layer + gpt * H, a.act_g + (size_t)l * act_layer + gpt * H, fr, h);
+            bwd_activation<NT>(g.v, a.act_c + (size_t)sub * act_layer + gpt * H, a.act_g + (size_t)sub * act_layer + gpt * H, fr, h);
+            --sub;
             if (l > 0) {
                 bwd_matrix<NT, NT>(wp, g.v, g2.v, lane);
                 wp += (size_t)NT * NT * TILE4;
@@ -704,27 +739,34 @@ static int field_grid(const void* kernel, long long total_tiles) {
     return (blocks + 7) / 8 * 8;
 }
 
-template <int NT>
+template <int NT, bool HAS_RES>
 static hipError_t launch_field_backward_nt(const FieldArgs& a, hipStream_t stream) {
-    const int blocks = field_grid((const void*)field_backward_kernel<NT>, a.total_tiles);
-    hipLaunchKernelGGL(field_backward_kernel<NT>, dim3(blocks), dim3(256), 0, stream, a);
+    const int blocks = field_grid((const void*)field_backward_kernel<NT, HAS_RES>, a.total_tiles);
+    hipLaunchKernelGGL((field_backward_kernel<NT, HAS_RES>), dim3(blocks), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 
+static bool has_res(const FieldArgs& a) {
+    bool res = false;
+    for (int l = 0; l < a.L; ++l) res |= a.layer_kind[l] == CNERF_LAYER_RES;
+    return res;
+}
+
 hipError_t launch_field_backward(const FieldArgs& a, int H, hipStream_t stream) {
+    const bool res = has_res(a);
     switch (H / 32) {
-        case 2: return launch_field_backward_nt<2>(a, stream);
-        case 4: return launch_field_backward_nt<4>(a, stream);
-        case 8: return launch_field_backward_nt<8>(a, stream);
+        case 2: return res ? launch_field_backward_nt<2, true>(a, stream) : launch_field_backward_nt<2, false>(a, stream);
+        case 4: return res ? launch_field_backward_nt<4, true>(a, stream) : launch_field_backward_nt<4, false>(a, stream);
+        case 8: return res ? launch_field_backward_nt<8, true>(a, stream) : launch_field_backward_nt<8, false>(a, stream);
         default: return hipErrorInvalidValue;
     }
 }
 
 template <int NT, bool HAS_RES>
 static hipError_t launch_field_nt(const FieldArgs& a, hipStream_t stream) {
-    if (a.act_h) {   // activation-storing forward of the backward pass (no residual blocks)
-        const int blocks = field_grid((const void*)field_tile_kernel<NT, false, true>, a.total_tiles);
-        hipLaunchKernelGGL((field_tile_kernel<NT, false, true>), dim3(blocks), dim3(256), 0, stream, a);
+    if (a.act_h) {   // activation-storing forward of the backward pass
+        const int blocks = field_grid((const void*)field_tile_kernel<NT, HAS_RES, true>, a.total_tiles);
+        hipLaunchKernelGGL((field_tile_kernel<NT, HAS_RES, true>), dim3(blocks), dim3(256), 0, stream, a);
     } else {
         const int blocks = field_grid((const void*)field_tile_kernel<NT, HAS_RES, false>, a.total_tiles);
         hipLaunchKernelGGL((field_tile_kernel<NT, HAS_RES, false>), dim3(blocks), dim3(256), 0, stream, a);
@@ -733,8 +775,7 @@ static hipError_t launch_field_nt(const FieldArgs& a, hipStream_t stream) {
 }
 
 hipError_t launch_field(const FieldArgs& a, int H, hipStream_t stream) {
-    bool res = false;
-    for (int l = 0; l < a.L; ++l) res |= a.layer_kind[l] == CNERF_LAYER_RES;
+    const bool res = has_res(a);
     switch (H / 32) {
         case 2: return res ? launch_field_nt<2, true>(a, stream) : launch_field_nt<2, false>(a, stream);
         case 4: return res ? launch_field_nt<4, true>(a, stream) : launch_field_nt<4, false>(a, stream);

@@ -303,10 +303,13 @@ def render_backward(net, o, levels, freq, phase, cam2world, rng, saved, grad_pix
             "cnerf_merge_composite_backward")
 
     params = net.field_params()
-    Ws, bs = [], []
+    Ws, bs, slab_of = [], [], []      # one entry per matrix ("slab"): a residual block contributes fc1 and fc2
     it = iter(params)
-    for _ in kinds:
-        Ws.append(next(it).detach()); bs.append(next(it).detach())
+    for kind in kinds:
+        for _ in range(2 if kind == "res" else 1):
+            Ws.append(next(it).detach()); bs.append(next(it).detach())
+            slab_of.append("sine" if kind == "res" else kind)
+    nslab = len(Ws)
     W_head = next(it).detach()
     dW = [torch.zeros_like(w) for w in Ws]
     db = [torch.zeros_like(b) for b in bs]
@@ -318,7 +321,7 @@ def render_backward(net, o, levels, freq, phase, cam2world, rng, saved, grad_pix
     grad_levels = [torch.zeros_like(v) for v in levels]
     gvs = volumes_struct(grad_levels)
 
-    per_image = npi * (32 * n_in + 3 * nl * H + 4) * 4
+    per_image = npi * (32 * n_in + 3 * nslab * H + 4) * 4
     nb = max(1, min(B, ACT_BUDGET_BYTES // per_image))
     act = None
     u_strat, fine_z_used = _f32(rng.get("u_strat")), f_z
@@ -329,9 +332,9 @@ def render_backward(net, o, levels, freq, phase, cam2world, rng, saved, grad_pix
             n = cnt * npi
             if act is None or act[0].shape[0] != n:
                 act = (torch.empty((n, 32 * n_in), dtype=torch.float32, device=dev),
-                       torch.empty((nl, n, H), dtype=torch.float32, device=dev),
-                       torch.empty((nl, n, H), dtype=torch.float32, device=dev),
-                       torch.empty((nl, n, H), dtype=torch.float32, device=dev),
+                       torch.empty((nslab, n, H), dtype=torch.float32, device=dev),
+                       torch.empty((nslab, n, H), dtype=torch.float32, device=dev),
+                       torch.empty((nslab, n, H), dtype=torch.float32, device=dev),
                        torch.empty((n, 4), dtype=torch.float32, device=dev))
             a_feat, a_h, a_c, a_g, a_go = act
             L.check(L.lib().cnerf_field_backward(C.byref(cfg), pss, b0, cnt, C.byref(vs), L.ptr(packed), L.ptr(packed_t),
@@ -341,7 +344,7 @@ def render_backward(net, o, levels, freq, phase, cam2world, rng, saved, grad_pix
                                                  C.byref(gvs), _stream()), "cnerf_field_backward")
             # parameter gradients: plain GEMMs and column sums over the chunk matrices (rocBLAS through torch)
             fidx = 0
-            for l, kind in enumerate(kinds):
+            for l, kind in enumerate(slab_of):
                 X = (a_feat if l == 0 else a_h[l - 1]).view(cnt, npi, -1)
                 G = a_g[l].view(cnt, npi, H)
                 dWarg = torch.bmm(G.transpose(1, 2), X)          # (cnt, H, K) per image
@@ -359,10 +362,10 @@ def render_backward(net, o, levels, freq, phase, cam2world, rng, saved, grad_pix
                 else:
                     dW[l] += dWarg.sum(0)
                     db[l] += cs.sum(0)
-            dW_head += a_go.t() @ a_h[nl - 1]
+            dW_head += a_go.t() @ a_h[nslab - 1]
             db_head += a_go.sum(0)
     grads = []
-    for l in range(nl):
+    for l in range(nslab):
         grads += [dW[l], db[l]]
     grads += [dW_head, db_head]
     return grad_levels, g_freq, g_phase, grads

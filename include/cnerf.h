@@ -188,7 +188,8 @@ int cnerf_render_forward(const cnerf_cfg* cfg, const cnerf_volumes* vols, const 
  *             dWarg_l = act_g[l]^T x_{l-1};  dW_l = diag(freq_l) dWarg_l;  db_l = freq_l * colsum(act_g[l])
  *             dphase_l = colsum(act_g[l]);   dfreq_l = rowsum(W_l * dWarg_l) + b_l * dphase_l   (per image)
  *             dW_head = act_go^T x_L;        db_head = colsum(act_go)
- * Residual (CNERF_LAYER_RES) networks are not supported by the backward yet: CNERF_ENOSYS. */
+ * A residual block owns two consecutive slabs of act_h / act_c / act_g (fc1 then fc2); L in the shapes above then counts
+ * slabs:  dW_fc1 = act_g[s]^T x_in, dW_fc2 = act_g[s+1]^T act_h[s]. */
 
 /* packed_t: transposed packed weights for the backward; bytes via cnerf_backward_bytes. */
 int cnerf_backward_bytes(const cnerf_cfg* cfg, size_t* packed_t);

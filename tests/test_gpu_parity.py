@@ -227,7 +227,7 @@ def test_render_free_running(golden, dev, name):
 
 
 GRAD_FIXTURES = [n for n in GOLDEN_NAMES if n.endswith("_small") or n in ("short_fg_nohier", "short_fg_s40")]
-RES_FIXTURES = {"short_fres_small", "tall_dres_small"}
+RES_FIXTURES = set()      # residual-block networks have a backward too
 
 
 def reference_grad_noise_floor(g):
@@ -301,19 +301,6 @@ def test_backward_teacher_forced(golden, dev, name):
     for k, p in gen.named_parameters():
         assert p.grad is not None, k
         assert scaled_err(p.grad.cpu().numpy(), ref[k]) < tol(k), k
-
-
-def test_backward_residual_not_supported(golden, dev):
-    """Residual-block networks run forward; their backward says so instead of returning something wrong."""
-    import cnerf_amd
-    g = golden("short_fres_small")
-    gen = make_generator(g, dev)
-    fvol = G(g["feature_volume"], dev).requires_grad_(True)
-    m = g.meta
-    pixels, depth = gen(fvol, G(g["cam2worlds"], dev), m["R"], m["fov"], m["ray_start"], m["ray_end"], m["S"], True,
-                        clamp_mode="relu", nerf_noise=0.0)
-    with pytest.raises(cnerf_amd._lib.CnerfError):
-        pixels.mean().backward()
 
 
 def test_render_matches_oracle_random_inputs(dev):
