@@ -10,8 +10,8 @@ MAX_LAYERS = 16
 MAX_LEVELS = 4
 ABI_VERSION = 2
 F_HIERARCHICAL, F_WHITE_BACK, F_LAST_BACK, F_SOFTPLUS, F_SIGMOID_RGB, F_INPUT_XYZ = 1, 2, 4, 8, 16, 32
-LAYER_FILM, LAYER_SINE, LAYER_RES = 0, 1, 2
-LAYER_CODE = {"film": LAYER_FILM, "sine": LAYER_SINE, "res": LAYER_RES}
+LAYER_FILM, LAYER_SINE, LAYER_RES, LAYER_PFILM = 0, 1, 2, 3
+LAYER_CODE = {"film": LAYER_FILM, "sine": LAYER_SINE, "res": LAYER_RES, "pfilm": LAYER_PFILM}
 
 
 class Cfg(C.Structure):
@@ -28,7 +28,8 @@ class Volumes(C.Structure):
 
 class FieldParams(C.Structure):
     _fields_ = [("w", C.c_void_p * MAX_LAYERS), ("b", C.c_void_p * MAX_LAYERS), ("w2", C.c_void_p * MAX_LAYERS),
-                ("b2", C.c_void_p * MAX_LAYERS), ("w_final", C.c_void_p), ("b_final", C.c_void_p)]
+                ("b2", C.c_void_p * MAX_LAYERS), ("w_final", C.c_void_p), ("b_final", C.c_void_p),
+                ("map_w1", C.c_void_p), ("map_b1", C.c_void_p), ("map_w2", C.c_void_p), ("map_b2", C.c_void_p)]
 
 
 class Rng(C.Structure):

@@ -46,8 +46,10 @@ int check_cfg(const cnerf_cfg* c, bool need_render) {
     if (c->L < 1 || c->L > CNERF_MAX_LAYERS) return fail(CNERF_EINVAL, "L=%d out of range [1,%d]", c->L, CNERF_MAX_LAYERS);
     for (int l = 0; l < c->L; ++l) {
         const int k = c->layer_kind[l];
-        if (k != CNERF_LAYER_FILM && k != CNERF_LAYER_SINE && k != CNERF_LAYER_RES)
+        if (k != CNERF_LAYER_FILM && k != CNERF_LAYER_SINE && k != CNERF_LAYER_RES && k != CNERF_LAYER_PFILM)
             return fail(CNERF_EINVAL, "layer_kind[%d]=%d unknown", l, k);
+        if ((k == CNERF_LAYER_PFILM) != (c->layer_kind[0] == CNERF_LAYER_PFILM))
+            return fail(CNERF_EINVAL, "per-point FiLM layers cannot be mixed with other layer kinds");
         if (l == 0 && k == CNERF_LAYER_RES) return fail(CNERF_EINVAL, "layer 0 cannot be a residual block");
     }
     if (!(c->voxel_length > 0.f)) return fail(CNERF_EINVAL, "voxel_length must be > 0");
@@ -77,6 +79,19 @@ PackedLayout packed_layout(const cnerf_cfg* c) {
     const size_t NT = c->H / 32;
     const size_t tile = 4 * 64 * 4;  // floats per (t, tk) pair
     PackedLayout p{0, 0, 0, 0, 0};
+    if (c->layer_kind[0] == CNERF_LAYER_PFILM) {   // mapping hidden | per layer (main, freq rows, phase rows) | head
+        p.n_in = 1;
+        p.k0 = 3;
+        p.weight_floats = 8 * tile;
+        p.bias_floats = 256;
+        for (int l = 0; l < c->L; ++l) {
+            p.weight_floats += NT * (l == 0 ? 1 : NT) * tile + 2 * NT * 8 * tile;
+            p.bias_floats += 3 * c->H;
+        }
+        p.weight_floats += NT * tile;
+        p.bias_floats += 4;
+        return p;
+    }
     p.n_in = c->C / 32 + ((c->flags & CNERF_F_INPUT_XYZ) ? 1 : 0);
     p.k0 = c->C + ((c->flags & CNERF_F_INPUT_XYZ) ? 3 : 0);
     for (int l = 0; l < c->L; ++l) {
@@ -207,6 +222,39 @@ int cnerf_pack_field(const cnerf_cfg* cfg, const cnerf_field_params* p, float* p
     float* wdst = packed;
     float* bdst = packed + pl.weight_floats;
     const size_t tile = 4 * 64 * 4;
+    if (cfg->layer_kind[0] == CNERF_LAYER_PFILM) {
+        if (cfg->C != 32 || cfg->n_levels > 1) return fail(CNERF_EINVAL, "per-point FiLM: a single 32-channel feature volume is supported");
+        if (!p->map_w1 || !p->map_b1 || !p->map_w2 || !p->map_b2 || !p->w_final || !p->b_final)
+            return fail(CNERF_EINVAL, "pack_field: mapping network / head is NULL");
+        auto cp = [&](const float* src, size_t n) { return hipMemcpyAsync(bdst, src, n * sizeof(float), hipMemcpyDeviceToDevice, stream); };
+        if (hipError_t e = launch_pack_matrix(p->map_w1, 256, cfg->C, 8, wdst, stream)) return hip_fail(e, "pack_matrix");
+        wdst += 8 * tile;
+        if (hipError_t e = cp(p->map_b1, 256)) return hip_fail(e, "bias copy");
+        bdst += 256;
+        const size_t LH = (size_t)cfg->L * H;
+        for (int l = 0; l < cfg->L; ++l) {
+            const int K = (l == 0) ? 3 : H;
+            if (!p->w[l] || !p->b[l]) return fail(CNERF_EINVAL, "pack_field: layer %d weight/bias is NULL", l);
+            if (hipError_t e = launch_pack_matrix(p->w[l], H, K, NT, wdst, stream)) return hip_fail(e, "pack_matrix");
+            wdst += (size_t)NT * ((K + 31) / 32) * tile;
+            if (hipError_t e = launch_pack_matrix(p->map_w2 + (size_t)l * H * 256, H, 256, NT, wdst, stream)) return hip_fail(e, "pack_matrix");
+            wdst += (size_t)NT * 8 * tile;
+            if (hipError_t e = launch_pack_matrix(p->map_w2 + (LH + (size_t)l * H) * 256, H, 256, NT, wdst, stream)) return hip_fail(e, "pack_matrix");
+            wdst += (size_t)NT * 8 * tile;
+            if (hipError_t e = cp(p->b[l], H)) return hip_fail(e, "bias copy");
+            bdst += H;
+            if (hipError_t e = cp(p->map_b2 + (size_t)l * H, H)) return hip_fail(e, "bias copy");
+            bdst += H;
+            if (hipError_t e = cp(p->map_b2 + LH + (size_t)l * H, H)) return hip_fail(e, "bias copy");
+            bdst += H;
+        }
+        if (hipError_t e = launch_pack_matrix(p->w_final, 4, H, 1, wdst, stream)) return hip_fail(e, "pack_matrix");
+        if (hipError_t e = cp(p->b_final, 4)) return hip_fail(e, "bias copy");
+        bdst += 4;
+        if (hipError_t e = launch_fill(bdst, 1.0f, H, stream)) return hip_fail(e, "fill");
+        if (hipError_t e = launch_fill(bdst + H, 0.0f, H, stream)) return hip_fail(e, "fill");
+        return CNERF_OK;
+    }
     for (int l = 0; l < cfg->L; ++l) {
         const int K = (l == 0) ? pl.k0 : H;                    // layer 0: C (+3), zero padded to 32 * n_in columns
         if (!p->w[l] || !p->b[l]) return fail(CNERF_EINVAL, "pack_field: layer %d weight/bias is NULL", l);
@@ -366,6 +414,7 @@ int cnerf_backward_bytes(const cnerf_cfg* cfg, size_t* packed_t) {
 int cnerf_pack_field_transposed(const cnerf_cfg* cfg, const cnerf_field_params* p, float* packed_t, void* stream_) {
     g_err[0] = 0;
     if (int rc = check_cfg(cfg, false)) return rc;
+    if (cfg->layer_kind[0] == CNERF_LAYER_PFILM) return fail(CNERF_ENOSYS, "backward of the per-point FiLM family is not implemented");
     if (!p || !packed_t) return fail(CNERF_EINVAL, "pack_field_transposed: NULL argument");
     hipStream_t stream = (hipStream_t)stream_;
     const int H = cfg->H, NT = H / 32;
@@ -413,6 +462,7 @@ int cnerf_field_backward(const cnerf_cfg* cfg, int32_t pass, int32_t image0, int
                          float* act_c, float* act_g, float* act_go, const cnerf_grad_volumes* grad_vols, void* stream_) {
     g_err[0] = 0;
     if (int rc = check_cfg(cfg, true)) return rc;
+    if (cfg->layer_kind[0] == CNERF_LAYER_PFILM) return fail(CNERF_ENOSYS, "backward of the per-point FiLM family is not implemented");
     if (image0 < 0 || n_images < 1 || image0 + n_images > cfg->B) return fail(CNERF_EINVAL, "field_backward: image range out of [0,B)");
     if (pass < 0 || pass > 2) return fail(CNERF_EINVAL, "field_backward: pass must be 0 (coarse), 1 (fine) or 2 (explicit points)");
     if (!vols || !packed || !packed_t || !cam2world || !grad_rgb_sigma || !saved_rgb_sigma || !act_feat || !act_h || !act_c ||

@@ -477,6 +477,133 @@ __global__ __launch_bounds__(256) void field_tile_kernel(FieldArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Per-point FiLM family (TALLSIREN, siren.py:232-331): layer input = world xyz; frequencies and phases of every layer
+// come per POINT from a mapping MLP of the looked-up feature:  m = LeakyReLU_0.2(Wm1 feat + bm1) (256 wide),
+// [freq | phase] = Wm2 m + bm2 (2*L*H wide), freq = freq*15+30.  The 2*L*H mapping outputs are never materialised: for
+// output tile t of layer l the kernel runs three accumulations -- W_l x, Wm2[freq rows] m, Wm2[phase rows] m -- and
+// combines them in the epilogue.  Forward only (its backward is not written: CNERF_ENOSYS).
+// Packed stream: Wm1 (8 x 1 tiles) | per layer: W_l (NT x KT), Wm2 freq rows (NT x 8), Wm2 phase rows (NT x 8) | head.
+// Bias stream:   bm1 (256) | per layer: b_l (H), bm2 freq slice (H), bm2 phase slice (H) | head bias (4).
+// ---------------------------------------------------------------------------------------------------------------
+template <int KT>
+__device__ __forceinline__ f32x16 mfma_accumulate(const f32x4* __restrict__ wp, const f32x16* in, f32x16 acc, int lane) {
+    constexpr int NG = KT * 4;
+    f32x4 ring[RING];
+#pragma unroll
+    for (int i = 0; i < RING; ++i)
+        if (i < NG) ring[i] = wp[i * 64 + lane];
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+        const int tk = i >> 2, g = i & 3;
+        const f32x4 aw = ring[i % RING];
+        if (i + RING < NG) ring[i % RING] = wp[(i + RING) * 64 + lane];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[e], in[tk][4 * g + e], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    return acc;
+}
+
+template <int NT, int KT>
+__device__ __forceinline__ void pfilm_layer(const f32x4* __restrict__ w_main, const f32x4* __restrict__ w_freq,
+                                            const f32x4* __restrict__ w_phase, const float* __restrict__ b_main,
+                                            const float* __restrict__ b_freq, const float* __restrict__ b_phase,
+                                            const f32x16* x, const f32x16* m, f32x16* y, int lane, int h) {
+    constexpr size_t TILE4 = 4 * 64;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        f32x16 fr = mfma_accumulate<8>(w_freq + (size_t)t * 8 * TILE4, m, load_chan16(b_freq, t, h), lane);
+        f32x16 ph = mfma_accumulate<8>(w_phase + (size_t)t * 8 * TILE4, m, load_chan16(b_phase, t, h), lane);
+        f32x16 pre = mfma_accumulate<KT>(w_main + (size_t)t * KT * TILE4, x, load_chan16(b_main, t, h), lane);
+        f32x16 o;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] = sin_pi_reduced((fr[r] * 15.0f + 30.0f) * pre[r] + ph[r]);
+        y[t] = o;
+    }
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void field_pw_kernel(FieldArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int j = lane & 31, h = lane >> 5;
+    constexpr int H = NT * 32;
+    constexpr size_t TILE4 = 4 * 64;
+    const TileRange tr = tile_range(a.total_tiles);
+    for (long long tile = tr.begin; tile < tr.end; tile += tr.stride) {
+        const int b = (int)(tile / a.tiles_per_image);
+        const long long n = (tile - (long long)b * a.tiles_per_image) * 32 + j;
+        const bool valid = n < a.n_per_image;
+        const long long nn = valid ? n : (a.n_per_image - 1);
+        float px, py, pz;
+        tile_point(a, b, nn, valid, h, true, px, py, pz);
+
+        const f32x4* wp = reinterpret_cast<const f32x4*>(a.packed);
+        const float* bias = a.bias;
+        // mapping hidden layer: 256 wide, LeakyReLU(0.2)
+        Act<8> m;
+        {
+            const f32x16 feat = input_tile(a, b, 0, px, py, pz, h);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) m.v[t] = load_chan16(bias, t, h);
+            layer0_accumulate<8>(wp, 1, 0, feat, m.v, lane);
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) m.v[t][r] = m.v[t][r] > 0.0f ? m.v[t][r] : m.v[t][r] * 0.2f;
+            wp += 8 * TILE4;
+            bias += 256;
+        }
+        Act<NT> x, y;
+        f32x16 xyz;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xyz[r] = 0.0f;
+        if (h == 0) {
+            xyz[0] = px;
+            xyz[1] = py;
+            xyz[2] = pz;
+        }
+        for (int l = 0; l < a.L; ++l) {
+            if (l == 0) {
+                const f32x4* w_main = wp;
+                const f32x4* w_freq = w_main + (size_t)NT * 1 * TILE4;
+                const f32x4* w_phase = w_freq + (size_t)NT * 8 * TILE4;
+                pfilm_layer<NT, 1>(w_main, w_freq, w_phase, bias, bias + H, bias + 2 * H, &xyz, m.v, x.v, lane, h);
+                wp = w_phase + (size_t)NT * 8 * TILE4;
+            } else {
+                const f32x4* w_main = wp;
+                const f32x4* w_freq = w_main + (size_t)NT * NT * TILE4;
+                const f32x4* w_phase = w_freq + (size_t)NT * 8 * TILE4;
+                pfilm_layer<NT, NT>(w_main, w_freq, w_phase, bias, bias + H, bias + 2 * H, x.v, m.v, y.v, lane, h);
+                wp = w_phase + (size_t)NT * 8 * TILE4;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) x.v[t] = y.v[t];
+            }
+            bias += 3 * H;
+        }
+        // head
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        if (h == 0) {
+            acc[0] = bias[0];
+            acc[1] = bias[1];
+            acc[2] = bias[2];
+            acc[3] = bias[3];
+        }
+        acc = mfma_accumulate<NT>(wp, x.v, acc, lane);
+        if (valid && h == 0) {
+            f32x4 o;
+            const bool sg = a.flags & CNERF_F_SIGMOID_RGB;
+            o[0] = sg ? sigmoidf_(acc[0]) : acc[0];
+            o[1] = sg ? sigmoidf_(acc[1]) : acc[1];
+            o[2] = sg ? sigmoidf_(acc[2]) : acc[2];
+            o[3] = acc[3];
+            *reinterpret_cast<f32x4*>(a.rgb_sigma + ((size_t)b * a.n_per_image + nn) * 4) = o;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Backward of the point pass for one 32-point tile per wave (FiLM / sine layers; residual blocks are not supported yet).
 //
 //   go' = d loss / d head pre-activation (sigmoid' applied)                          -> act_go (n,4)
@@ -774,7 +901,22 @@ static hipError_t launch_field_nt(const FieldArgs& a, hipStream_t stream) {
     return hipGetLastError();
 }
 
+template <int NT>
+static hipError_t launch_field_pw_nt(const FieldArgs& a, hipStream_t stream) {
+    const int blocks = field_grid((const void*)field_pw_kernel<NT>, a.total_tiles);
+    hipLaunchKernelGGL(field_pw_kernel<NT>, dim3(blocks), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
 hipError_t launch_field(const FieldArgs& a, int H, hipStream_t stream) {
+    if (a.layer_kind[0] == CNERF_LAYER_PFILM) {
+        switch (H / 32) {
+            case 2: return launch_field_pw_nt<2>(a, stream);
+            case 4: return launch_field_pw_nt<4>(a, stream);
+            case 8: return launch_field_pw_nt<8>(a, stream);
+            default: return hipErrorInvalidValue;
+        }
+    }
     const bool res = has_res(a);
     switch (H / 32) {
         case 2: return res ? launch_field_nt<2, true>(a, stream) : launch_field_nt<2, false>(a, stream);

@@ -167,14 +167,15 @@ class PointwiseFiLMLayer(_LinearSine):
     kind = "pfilm"
 
 
-class TALLSIREN(nn.Module):
+class TALLSIREN(FieldNetwork):
     """pi-GAN style field (siren.py:232-331): input = world xyz, eight FiLM layers whose frequencies / phases come per
-    POINT from a mapping MLP of the looked-up feature.  Parameters, names and initialisation mirror the reference so its
-    checkpoints load; the HIP kernel for this family is not written yet, so evaluating it raises NotImplementedError."""
+    POINT from a mapping MLP of the looked-up feature (z is the bare feature volume, z_dim = its channel count).
+    Parameters, names and initialisation mirror the reference so its checkpoints load.  Forward only on the GPU so far."""
     variant = "TALLSIREN"
+    spec = FieldSpec(("pfilm",) * 8, 25, False, False, False, "xyz")
 
     def __init__(self, input_dim=3, z_dim=100, hidden_dim=256, output_dim=4, drop_out=0, device=None, **kwargs):
-        super().__init__()
+        nn.Module.__init__(self)
         self.device = device
         self.input_dim, self.z_dim, self.hidden_dim, self.output_dim = input_dim, z_dim, hidden_dim, output_dim
         self.drop_out = drop_out
@@ -186,11 +187,17 @@ class TALLSIREN(nn.Module):
         _uniform_weights(self.final_layer, lambda n: math.sqrt(6 / n) / 25)
         _uniform_weights(self.network[0], lambda n: 1 / n)
 
-    def check_supported(self):
-        raise NotImplementedError("TALLSIREN (per-point FiLM mapping network) has no HIP kernel yet")
+    def field_params(self):
+        mp = self.mapping_network.network
+        out = [mp[0].weight, mp[0].bias, mp[2].weight, mp[2].bias]
+        for blk in self.network:
+            out += [blk.layer.weight, blk.layer.bias]
+        return out + [self.final_layer.weight, self.final_layer.bias]
 
-    def forward(self, points, z, img_size=None, num_steps=None):
-        self.check_supported()
+    def check_supported(self):
+        super().check_supported()
+        if self.input_dim != 3:
+            raise NotImplementedError("TALLSIREN reads the world position: input_dim must be 3")
 
 
 def _make(name):

@@ -51,7 +51,7 @@ def make_cfg(net, B, vols, R=1, S=2, fov=30.0, ray_start=0.0, ray_end=1.0, noise
     cfg.n_levels = len(shapes)
     for i, (v, c) in enumerate(shapes):
         cfg.level_V[i], cfg.level_C[i] = v, c
-    k0 = cfg.C + (3 if net.spec.input == "feat_xyz" else 0)
+    k0 = 3 if net.spec.input == "xyz" else cfg.C + (3 if net.spec.input == "feat_xyz" else 0)
     if not isinstance(vols, int) and k0 != int(net.input_dim):
         raise L.CnerfError(f"{net.variant}: layer 0 expects {net.input_dim} inputs, the feature volumes provide {k0}")
     kinds = [L.LAYER_CODE[k] for k in net.spec.layers]
@@ -81,6 +81,20 @@ def sizes(cfg, render=True):
     return a.value, b.value, c.value
 
 
+def _field_params_struct(net, params):
+    """cnerf_field_params from the flat tensor list of net.field_params() (mapping MLP first for the per-point family)."""
+    fp = L.FieldParams()
+    it = iter(params)
+    if net.spec.input == "xyz":
+        fp.map_w1, fp.map_b1, fp.map_w2, fp.map_b2 = (next(it).data_ptr() for _ in range(4))
+    for i, kind in enumerate(net.spec.layers):
+        fp.w[i], fp.b[i] = next(it).data_ptr(), next(it).data_ptr()
+        if kind == "res":
+            fp.w2[i], fp.b2[i] = next(it).data_ptr(), next(it).data_ptr()
+    fp.w_final, fp.b_final = next(it).data_ptr(), next(it).data_ptr()
+    return fp
+
+
 def pack_field(net, cfg):
     """Packed MFMA-order weights of `net` (device tensor), re-packed only when a parameter changed."""
     params = [_f32(p.detach()) for p in net.field_params()]
@@ -90,13 +104,7 @@ def pack_field(net, cfg):
         return hit[1]
     nbytes, _, _ = sizes(cfg, render=False)
     packed = torch.empty(nbytes // 4, dtype=torch.float32, device=params[0].device)
-    fp = L.FieldParams()
-    it = iter(params)
-    for i, kind in enumerate(net.spec.layers):
-        fp.w[i], fp.b[i] = next(it).data_ptr(), next(it).data_ptr()
-        if kind == "res":
-            fp.w2[i], fp.b2[i] = next(it).data_ptr(), next(it).data_ptr()
-    fp.w_final, fp.b_final = next(it).data_ptr(), next(it).data_ptr()
+    fp = _field_params_struct(net, params)
     L.check(L.lib().cnerf_pack_field(C.byref(cfg), C.byref(fp), L.ptr(packed), _stream()), "cnerf_pack_field")
     packed._keepalive = params
     _pack_cache[id(net)] = (key, packed)
@@ -260,13 +268,7 @@ def pack_field_transposed(net, cfg):
     nb = C.c_size_t(0)
     L.check(L.lib().cnerf_backward_bytes(C.byref(cfg), C.byref(nb)), "cnerf_backward_bytes")
     packed_t = torch.empty(nb.value // 4, dtype=torch.float32, device=params[0].device)
-    fp = L.FieldParams()
-    it = iter(params)
-    for i, kind in enumerate(net.spec.layers):
-        fp.w[i], fp.b[i] = next(it).data_ptr(), next(it).data_ptr()
-        if kind == "res":
-            fp.w2[i], fp.b2[i] = next(it).data_ptr(), next(it).data_ptr()
-    fp.w_final, fp.b_final = next(it).data_ptr(), next(it).data_ptr()
+    fp = _field_params_struct(net, params)
     L.check(L.lib().cnerf_pack_field_transposed(C.byref(cfg), C.byref(fp), L.ptr(packed_t), _stream()),
             "cnerf_pack_field_transposed")
     packed_t._keepalive = params

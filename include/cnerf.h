@@ -44,6 +44,9 @@ extern "C" {
 #define CNERF_LAYER_FILM 0 /* y = sin(freq * (W x + b) + phase), freq/phase per image */
 #define CNERF_LAYER_SINE 1 /* y = sin(W x + b) */
 #define CNERF_LAYER_RES 2  /* y = sin(x + W2 sin(W1 x + b1) + b2) */
+#define CNERF_LAYER_PFILM 3 /* y = sin(freq(p) * (W x + b) + phase(p)): per-point FiLM from the mapping MLP of the looked-up
+                               feature (siren.py:163-177, 81-101); all layers of the network must be of this kind, layer 0
+                               then reads the world position (K = 3) and the features feed the mapping MLP only */
 
 typedef struct cnerf_cfg {
     int32_t B;            /* images in this call */
@@ -85,6 +88,11 @@ typedef struct cnerf_field_params {
     const float* b2[CNERF_MAX_LAYERS];
     const float* w_final; /* [4][H] */
     const float* b_final; /* [4] */
+    /* per-point FiLM family only (siren.mapping_network.network.{0,2}, siren.py:81-101) */
+    const float* map_w1;  /* [256][C]      */
+    const float* map_b1;  /* [256]         */
+    const float* map_w2;  /* [2*L*H][256]  freq rows first, then phase rows */
+    const float* map_b2;  /* [2*L*H]       */
 } cnerf_field_params;
 
 /* The four random tensors the reference draws, in its draw order; any may be NULL:

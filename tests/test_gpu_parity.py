@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import GOLDEN_NAMES as ALL_GOLDEN, SMALL_GOLDEN as ALL_SMALL, NOT_ON_GPU_YET, scaled_err
+from conftest import GOLDEN_NAMES as ALL_GOLDEN, SMALL_GOLDEN as ALL_SMALL, NOT_ON_GPU_YET, NO_BACKWARD_YET, scaled_err
 
 GOLDEN_NAMES = [n for n in ALL_GOLDEN if n not in NOT_ON_GPU_YET]
 SMALL_GOLDEN = [n for n in ALL_SMALL if n not in NOT_ON_GPU_YET]
@@ -227,7 +227,7 @@ def test_render_free_running(golden, dev, name):
 
 
 GRAD_FIXTURES = [n for n in GOLDEN_NAMES if n.endswith("_small") or n in ("short_fg_nohier", "short_fg_s40")]
-RES_FIXTURES = set()      # residual-block networks have a backward too
+RES_FIXTURES = set(NO_BACKWARD_YET)      # (residual-block networks have a backward too)
 
 
 def reference_grad_noise_floor(g):
