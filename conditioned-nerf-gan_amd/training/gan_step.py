@@ -1,0 +1,140 @@
+"""One GAN step around the HIP generator (counterpart of Trainer.train_discriminator / train_generator / set_alpha,
+utils.py:610-842 of the reference, which is not importable: F4 of SURVEY.md).  fp32 throughout (the reference's CUDA AMP
+has no place here: the render path is fp32 by contract), Adam(beta = (0, 0.9)), non-saturating logistic losses
+softplus(+-pred), R1 penalty on real images, gradient clipping, `batch_split` gradient accumulation.  Under
+torch.distributed every rank trains on its own images; DDP (backend "nccl" = RCCL over xGMI) averages the gradients, and
+all but the last accumulation chunk run under no_sync() so there is one all-reduce per optimizer step (the reference
+all-reduces on every chunk)."""
+import contextlib
+import math
+
+import torch
+import torch.nn.functional as F
+from torch.nn.parallel import DistributedDataParallel as DDP
+
+from ..generators import ImplicitGenerator3d
+from ..generators.volumetric_rendering import create_cam2world_matrix, sample_camera_positions
+from .discriminator import ProgressiveDiscriminator
+from .encoder import UNet3D
+
+
+def default_metadata(img_size=128, num_steps=64, batch_size=8, batch_split=4, siren_type="SHORTSIREN_FG", hidden_dim=256):
+    """The render / optimisation hyper-parameters of configs/thousand/{default,special}.py for the direct-feature-volume
+    setting (unet3d encoder -> (feature volume, global feature) -> FG field networks)."""
+    return {
+        "img_size": img_size, "num_steps": num_steps, "batch_size": batch_size, "batch_split": batch_split,
+        "fov": 49.134342641202636, "ray_start": 0.25, "ray_end": 1.95, "cam_r_start": 0.7, "cam_r_end": 1.5,
+        "white_back": True, "last_back": False, "clamp_mode": "relu", "hierarchical_sample": True, "nerf_noise": 1.0,
+        "fade_steps": 2000, "r1_lambda": 10, "grad_clip": 1, "betas": (0.0, 0.9), "weight_decay": 0,
+        "gen_lr": 5e-5, "disc_lr": 2e-4, "enc_lr": 5e-5, "photo_loss": True, "enable_discriminator": True,
+        "random_gen_img": True,
+        "generator": {"siren_type": siren_type, "z_dim": 256, "input_dim": 32, "output_dim": 4, "hidden_dim": hidden_dim},
+        "unet": {"in_channels": 4, "out_channels": 32, "f_maps": 32, "num_levels": 4, "return_global": True},
+    }
+
+
+class GanTrainer:
+    def __init__(self, metadata, device, ddp=False):
+        self.metadata, self.device, self.ddp = metadata, device, ddp
+        self.generator = ImplicitGenerator3d(**metadata["generator"]).to(device)
+        self.generator.set_device(device)
+        self.encoder = UNet3D(**metadata["unet"]).to(device)
+        self.discriminator = ProgressiveDiscriminator().to(device)
+        wrap = (lambda m, unused: DDP(m, device_ids=[device.index], find_unused_parameters=unused)) if ddp else (lambda m, unused: m)
+        self.generator_ddp = wrap(self.generator, True)
+        self.encoder_ddp = wrap(self.encoder, False)
+        self.discriminator_ddp = wrap(self.discriminator, True)
+        adam = lambda m, lr: torch.optim.Adam(m.parameters(), lr=lr, betas=metadata["betas"], weight_decay=metadata["weight_decay"])
+        self.optimizer_G = adam(self.generator_ddp, metadata["gen_lr"])
+        self.optimizer_E = adam(self.encoder_ddp, metadata["enc_lr"])
+        self.optimizer_D = adam(self.discriminator_ddp, metadata["disc_lr"])
+        self.alpha = 1.0
+        self.losses = {"d": [], "g": [], "photo": []}
+
+    # utils.py:610-618
+    def set_alpha(self, step_last_upsample=0):
+        step = self.generator.step
+        self.alpha = min(1.0, (step - step_last_upsample) / self.metadata["fade_steps"]) if self.metadata["fade_steps"] > 0 else 1.0
+        self.metadata["nerf_noise"] = max(0.0, 1.0 - step / 5000.0)
+
+    def _render(self, voxels, cams):
+        z = self.encoder_ddp(voxels)
+        return self.generator_ddp(z, cams, **self.metadata)
+
+    def _chunks(self, n):
+        size = n // self.metadata["batch_split"]
+        return [slice(i * size, (i + 1) * size) for i in range(self.metadata["batch_split"])]
+
+    # utils.py:743-842
+    def train_discriminator(self, sample):
+        md = self.metadata
+        real = sample["img"].to(self.device).requires_grad_(True)
+        voxels = sample["voxel"].to(self.device)
+        n = real.shape[0]
+        with torch.no_grad():
+            if md.get("random_gen_img", True):
+                cams = create_cam2world_matrix(sample_camera_positions(self.device, "y", md["cam_r_start"], md["cam_r_end"], n), "y", self.device)
+            else:
+                cams = sample["cam2world"].to(self.device)
+            fake = torch.cat([self._render(voxels[c], cams[c])[0] for c in self._chunks(n)], 0)
+        r_preds = self.discriminator_ddp(real, self.alpha, **md)
+        penalty = 0.0
+        if md["r1_lambda"] > 0:
+            (grad_real,) = torch.autograd.grad(r_preds.sum(), real, create_graph=True)
+            penalty = 0.5 * md["r1_lambda"] * grad_real.reshape(n, -1).norm(2, dim=1).pow(2).mean()
+        g_preds = self.discriminator_ddp(fake, self.alpha, **md)
+        d_loss = F.softplus(g_preds).mean() + F.softplus(-r_preds).mean() + penalty
+        self.optimizer_D.zero_grad()
+        d_loss.backward()
+        torch.nn.utils.clip_grad_norm_(self.discriminator_ddp.parameters(), md["grad_clip"])
+        self.optimizer_D.step()
+        self.losses["d"].append(d_loss.item())
+
+    # utils.py:621-741
+    def train_generator(self, sample):
+        md = self.metadata
+        imgs, cams, voxels = (sample[k].to(self.device) for k in ("img", "cam2world", "voxel"))
+        chunks = self._chunks(imgs.shape[0])
+        g_acc = p_acc = 0.0
+        for i, c in enumerate(chunks):
+            last = i == len(chunks) - 1
+            ctx = contextlib.ExitStack()
+            if self.ddp and not last:       # one all-reduce per optimizer step, not one per chunk
+                for m in (self.generator_ddp, self.encoder_ddp, self.discriminator_ddp):
+                    ctx.enter_context(m.no_sync())
+            with ctx:
+                gen_imgs, _ = self._render(voxels[c], cams[c])
+                if md["enable_discriminator"]:
+                    loss_g = F.softplus(-self.discriminator_ddp(gen_imgs, self.alpha, **md)).mean()
+                else:
+                    loss_g = gen_imgs.new_zeros(())
+                photo = F.mse_loss(gen_imgs, imgs[c]) if md["photo_loss"] else gen_imgs.new_zeros(())
+                (loss_g + photo).backward()
+            g_acc += loss_g.item()
+            p_acc += photo.item()
+        for model, opt in ((self.generator_ddp, self.optimizer_G), (self.encoder_ddp, self.optimizer_E)):
+            torch.nn.utils.clip_grad_norm_(model.parameters(), md.get("grad_clip", 0.3))
+            opt.step()
+            opt.zero_grad()
+        self.optimizer_D.zero_grad()        # the G step also left gradients in the discriminator
+        self.losses["g"].append(g_acc / len(chunks))
+        self.losses["photo"].append(p_acc / len(chunks))
+
+    def step(self, sample):
+        self.set_alpha()
+        if self.metadata["enable_discriminator"]:
+            self.train_discriminator(sample)
+        self.train_generator(sample)
+        self.generator.step += 1
+        self.discriminator.step += 1
+
+
+def synthetic_sample(batch, img_size, voxel_res, device, generator=None):
+    """ShapeNetCar-shaped random batch: voxels (B,4,V,V,V) = [occupancy, r, g, b] (datasets.py:105-110), images in [-1,1],
+    cameras on the training shell."""
+    g = generator
+    occ = (torch.rand(batch, 1, voxel_res, voxel_res, voxel_res, generator=g) > 0.9).float()
+    rgb = torch.rand(batch, 3, voxel_res, voxel_res, voxel_res, generator=g) * occ
+    cams = create_cam2world_matrix(sample_camera_positions("cpu", "y", 0.7, 1.5, batch), "y")
+    return {"voxel": torch.cat([occ, rgb], 1).to(device), "img": (torch.rand(batch, 3, img_size, img_size, generator=g) * 2 - 1).to(device),
+            "cam2world": cams.to(device)}

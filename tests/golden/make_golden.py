@@ -249,7 +249,25 @@ def build(name):
           f"depth[{depth.min():.3f},{depth.max():.3f}]")
 
 
+def build_unet3d():
+    """aux_unet3d_small.npz: the reference's UNet3D (generators/unet3d.py) on a tiny voxel grid, for the plain-PyTorch
+    encoder restatement of the training harness (conditioned-nerf-gan_amd/training/encoder.py)."""
+    sys.path.insert(0, REF)
+    from generators import unet3d
+    torch.manual_seed(0)
+    net = unet3d.UNet3D(in_channels=4, out_channels=16, f_maps=8, num_levels=3, final_sigmoid=False, is_segmentation=False,
+                        return_global=True)
+    net.eval()
+    vox = torch.rand(1, 4, 8, 8, 8)
+    with torch.no_grad():
+        fv, g = net(vox)
+    out = {"voxel": vox.numpy(), "feature_volume": fv.numpy(), "global_feature": g.numpy()}
+    for k, v in net.state_dict().items():
+        out["param/" + k] = v.numpy()
+    np.savez_compressed(os.path.join(HERE, "aux_unet3d_small.npz"), **out)
+
+
 if __name__ == "__main__":
     names = sys.argv[1:] or list(FIXTURES)
     for n in names:
-        build(n)
+        build_unet3d() if n == "unet3d" else build(n)

@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""GAN training loop around the MI355X render path on synthetic ShapeNetCar-shaped data (counterpart of the reference's
+train.py:58-143 + utils.Trainer; the reference's own `train.py -o test -p 1` needs its dataset and CUDA and does not even
+import: SURVEY.md F4).
+
+    python train.py --steps 2 --img-size 32 --num-steps 12 --batch 2 --batch-split 1 --hidden 64      # plumbing check
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 train.py    # 8 GPUs, DDP / RCCL
+
+One process per GPU; every rank draws its own images (seed = rank, like train.py:71 of the reference); gradients are
+averaged by DDP over RCCL once per optimizer step."""
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--img-size", type=int, default=128)
+    ap.add_argument("--num-steps", type=int, default=64)
+    ap.add_argument("--batch", type=int, default=8, help="images per GPU per step")
+    ap.add_argument("--batch-split", type=int, default=4)
+    ap.add_argument("--voxel-res", type=int, default=64)
+    ap.add_argument("--siren-type", default="SHORTSIREN_FG")
+    ap.add_argument("--hidden", type=int, default=256)
+    ap.add_argument("-p", "--print-freq", type=int, default=1)
+    args = ap.parse_args()
+
+    rank, local_rank, world = (int(os.environ.get(k, d)) for k, d in (("RANK", 0), ("LOCAL_RANK", 0), ("WORLD_SIZE", 1)))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    import __graft_entry__ as ge
+    if rank == 0:
+        ge.build()
+    if world > 1:
+        dist.barrier()
+    import cnerf_amd
+    from cnerf_amd.training import GanTrainer, default_metadata
+    from cnerf_amd.training.gan_step import synthetic_sample
+
+    torch.manual_seed(rank)
+    np.random.seed(rank)
+    md = default_metadata(args.img_size, args.num_steps, args.batch, args.batch_split, args.siren_type, args.hidden)
+    trainer = GanTrainer(md, dev, ddp=world > 1)
+    gen = torch.Generator().manual_seed(1000 + rank)
+    for step in range(args.steps):
+        sample = synthetic_sample(args.batch, args.img_size, args.voxel_res, dev, gen)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        trainer.step(sample)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if rank == 0 and step % args.print_freq == 0:
+            print(f"step {step}: D {trainer.losses['d'][-1]:.4f}  G {trainer.losses['g'][-1]:.4f}  photo {trainer.losses['photo'][-1]:.4f}  "
+                  f"alpha {trainer.alpha:.3f}  nerf_noise {md['nerf_noise']:.3f}  sec/step {dt:.3f}  "
+                  f"({world * args.batch * args.img_size ** 2 * 2 / dt / 1e6:.2f} M rays/s rendered, D + G passes)", flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
