@@ -343,6 +343,84 @@ def test_render_matches_oracle_random_inputs(dev):
     assert scaled_err(pixels.cpu().numpy(), ref.pixels.numpy()) < TOL
 
 
+def _oracle_case(dev, variant, B, R, S, V, H, clamp="relu", noise=0.0, white=True, last=False, seed=0, check_grads=False):
+    """Random inputs of an arbitrary shape: HIP vs the CPU oracle on the same rays / draws, fine depths forced."""
+    import cnerf_amd
+    from cnerf_amd.generators import ImplicitGenerator3d
+    from cnerf_amd.generators.volumetric_rendering import sample_camera_positions, create_cam2world_matrix
+    from oracle import render_oracle as O
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    Z = 32
+    has_glob = O.FIELD_SPECS[variant].has_global
+    gen = ImplicitGenerator3d(variant, Z if has_glob else 32, 32, 4, H)
+    with torch.no_grad():
+        gen.siren.final_layer.weight[3] *= 30
+    fvol, glob = torch.randn(B, 32, V, V, V) * 0.5, (torch.randn(B, Z) if has_glob else None)
+    cam = create_cam2world_matrix(sample_camera_positions("cpu", "y", 0.7, 1.5, B), "y")
+    P = R * R
+    rng = {"u_strat": torch.rand(B, P, S), "eps_coarse": torch.randn(B, P, S), "u_fine": torch.rand(B, P, S),
+           "eps_final": torch.randn(B, P, 2 * S)}
+    params = {k: v.detach() for k, v in gen.siren.state_dict().items()}
+    ref = O.render(variant, params, fvol, glob, cam, R, 49.13, 0.25, 1.95, S, True, clamp, noise, white, last,
+                   rng["u_strat"], rng["eps_coarse"], rng["u_fine"], rng["eps_final"])
+    gen.to(dev)
+    gen.set_device(dev)
+    r = {k: v.to(dev) for k, v in rng.items()}
+    r["fine_z"] = ref.aux["fine_z"].to(dev)
+    aux = {}
+    z = (fvol.to(dev), glob.to(dev)) if has_glob else fvol.to(dev)
+    with torch.no_grad():
+        px, dp = gen(z, cam.to(dev), R, 49.13, 0.25, 1.95, S, True, clamp_mode=clamp, nerf_noise=noise, white_back=white,
+                     last_back=last, _rng=r, _aux=aux)
+    assert torch.equal(aux["coarse_points"].cpu(), ref.aux["coarse_points"])
+    assert torch.equal(aux["fine_points"].cpu(), ref.aux["fine_points"])
+    assert torch.equal(aux["sort_idx"].cpu().long(), ref.aux["sort_idx"])
+    assert scaled_err(aux["coarse_rgb_sigma"].cpu().numpy(), ref.aux["coarse_rgb_sigma"].numpy()) < TOL
+    assert scaled_err(aux["fine_rgb_sigma"].cpu().numpy(), ref.aux["fine_rgb_sigma"].numpy()) < TOL
+    assert (aux["inds"].cpu() == ref.aux["inds"]).float().mean() > 0.99
+    if P > 1:      # (a single ray has no rms to scale by)
+        assert scaled_err(px.cpu().numpy(), ref.pixels.numpy()) < 2 * TOL
+        assert scaled_err(dp.cpu().numpy(), ref.depth.numpy()) < 2 * TOL
+    else:
+        assert np.abs(px.cpu().numpy() - ref.pixels.numpy()).max() < 2e-4
+
+
+@pytest.mark.parametrize("shape", [
+    dict(B=3, R=5, S=7, V=9),          # ragged: 175 points per image -> padded last tile, odd everything
+    dict(B=1, R=1, S=2, V=2),          # minimum sizes
+    dict(B=1, R=3, S=128, V=6),        # maximum samples per ray (four 64-lane chunks after the merge)
+    dict(B=2, R=6, S=33, V=5),         # samples straddle the 32-point tiles and the 64-lane chunks
+    dict(B=1, R=7, S=64, V=33),        # bench-like S, odd volume
+])
+def test_ragged_and_extreme_shapes(dev, shape):
+    _oracle_case(dev, "SHORTSIREN_FG", H=64, **shape)
+
+
+def test_extreme_shapes_other_families(dev):
+    _oracle_case(dev, "TALLSIREN_dRes", B=2, R=5, S=9, V=7, H=64, clamp="softplus", noise=0.4, last=True)
+    _oracle_case(dev, "DOUBLESIREN_FG", B=1, R=4, S=17, V=4, H=128, white=False)
+
+
+def test_bad_arguments_are_refused(dev):
+    """Shapes outside the supported range come back as CnerfError with a message, never as a wrong image."""
+    import cnerf_amd
+    from cnerf_amd.generators import ImplicitGenerator3d
+    gen = ImplicitGenerator3d("SHORTSIREN_FG", 16, 32, 4, 64).to(dev)
+    gen.set_device(dev)
+    fv, gl, cam = torch.zeros(1, 32, 4, 4, 4, device=dev), torch.zeros(1, 16, device=dev), torch.eye(4, device=dev)[None]
+    with pytest.raises(cnerf_amd._lib.CnerfError, match="S="):
+        gen((fv, gl), cam, 4, 30.0, 0.1, 1.0, 129, True, clamp_mode="relu", nerf_noise=0.0)
+    with pytest.raises(cnerf_amd._lib.CnerfError, match="S="):
+        gen((fv, gl), cam, 4, 30.0, 0.1, 1.0, 1, True, clamp_mode="relu", nerf_noise=0.0)
+    with pytest.raises(TypeError):
+        gen((fv, gl), cam, 4, 30.0, 0.1, 1.0, 8, True, clamp_mode=None, nerf_noise=0.0)
+    with pytest.raises(cnerf_amd._lib.CnerfError):
+        gen((torch.zeros(1, 16, 4, 4, 4, device=dev), gl), cam, 4, 30.0, 0.1, 1.0, 8, True, clamp_mode="relu", nerf_noise=0.0)
+    with pytest.raises(KeyError):            # the reference reads kwargs["clamp_mode"] unconditionally too
+        gen((fv, gl), cam, 4, 30.0, 0.1, 1.0, 8, True, nerf_noise=0.0)
+
+
 def test_full_size_properties(dev):
     """BASELINE size 128x128x64 (B=1): properties that need no oracle -- weights form a sub-probability, white
     background fills the missing mass, depth within [ray_start, ray_end]*dir_z, determinism across two runs."""
