@@ -248,7 +248,7 @@ int cnerf_pack_field(const cnerf_cfg* cfg, const cnerf_field_params* p, float* p
             if (hipError_t e = cp(p->map_b2 + LH + (size_t)l * H, H)) return hip_fail(e, "bias copy");
             bdst += H;
         }
-        if (hipError_t e = launch_pack_matrix(p->w_final, 4, H, 1, wdst, stream)) return hip_fail(e, "pack_matrix");
+        if (hipError_t e = launch_pack_head(p->w_final, H, wdst, stream)) return hip_fail(e, "pack_matrix");
         if (hipError_t e = cp(p->b_final, 4)) return hip_fail(e, "bias copy");
         bdst += 4;
         if (hipError_t e = launch_fill(bdst, 1.0f, H, stream)) return hip_fail(e, "fill");
@@ -271,7 +271,7 @@ int cnerf_pack_field(const cnerf_cfg* cfg, const cnerf_field_params* p, float* p
         }
     }
     if (!p->w_final || !p->b_final) return fail(CNERF_EINVAL, "pack_field: head is NULL");
-    if (hipError_t e = launch_pack_matrix(p->w_final, 4, H, 1, wdst, stream)) return hip_fail(e, "pack_matrix");
+    if (hipError_t e = launch_pack_head(p->w_final, H, wdst, stream)) return hip_fail(e, "pack_matrix");
     if (hipError_t e = hipMemcpyAsync(bdst, p->b_final, 4 * sizeof(float), hipMemcpyDeviceToDevice, stream)) return hip_fail(e, "bias copy");
     bdst += 4;
     if (hipError_t e = launch_fill(bdst, 1.0f, H, stream)) return hip_fail(e, "fill");

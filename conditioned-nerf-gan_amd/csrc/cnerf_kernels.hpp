@@ -62,6 +62,7 @@ hipError_t launch_pack_matrix(const float* w, int n_out, int K_real, int OT, flo
 hipError_t launch_field(const FieldArgs& a, int H, hipStream_t stream);
 hipError_t launch_field_backward(const FieldArgs& a, int H, hipStream_t stream);
 hipError_t launch_pack_head_t(const float* w, int H, float* dst, hipStream_t stream);
+hipError_t launch_pack_head(const float* w, int H, float* dst, hipStream_t stream);
 hipError_t launch_pack_matrix_t(const float* w, int n_rows_w, int n_cols_w, int OT, float* dst, hipStream_t stream);
 
 // ray_kernels.hip

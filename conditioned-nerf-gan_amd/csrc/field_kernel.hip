@@ -39,6 +39,22 @@ __global__ void pack_matrix_kernel(const float* __restrict__ w, int n_out, int K
     }
 }
 
+// Head (4 outputs) for v_mfma_f32_4x4x1_16B_f32: 16 independent 4x4 outer products per instruction.  Block b = lane/4
+// covers points 4b..4b+3 of the tile for lanes 0..31 and the same points again for lanes 32..63 (which hold the other
+// half of the channels), so the B operand is again an activation register as it stands; lane (b, i = lane&3) of the A
+// operand carries W_head[i][channel(s, lane>>5)].  float4 index (s/4)*64 + lane, element s%4; s = 16 t + r runs over the
+// activation registers (channel 32t + 8(r>>2) + 4h + (r&3)).
+__global__ void pack_head_kernel(const float* __restrict__ w, int H, float* __restrict__ dst) {
+    const int total = (H / 2) * 64;                 // H/2 registers per lane x 64 lanes
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < total) {
+        const int e = idx & 3, lane = (idx >> 2) & 63, q = idx >> 8;
+        const int sreg = 4 * q + e, t = sreg >> 4, r = sreg & 15, h = lane >> 5;
+        const int ch = 32 * t + 8 * (r >> 2) + 4 * h + (r & 3);
+        dst[idx] = w[(size_t)(lane & 3) * H + ch];
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // the point-tile kernel
 // ---------------------------------------------------------------------------------------------------------------
@@ -316,6 +332,31 @@ __device__ __forceinline__ TileRange tile_range(long long total_tiles) {
     return r;
 }
 
+// rgb_sigma pre-activations of the tile: returns, in lanes 0..31, the 4 head outputs of the lane's point.
+template <int NT>
+__device__ __forceinline__ f32x4 head_forward(const f32x4* __restrict__ wp, const float* __restrict__ bias, const f32x16* x,
+                                              int lane) {
+    f32x4 acc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < NT * 4; ++q) {                 // 4 activation registers per 16-byte weight load
+        const f32x4 aw = wp[q * 64 + lane];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int sreg = 4 * q + e;
+            acc[e] = __builtin_amdgcn_mfma_f32_4x4x1f32(aw[e], x[sreg >> 4][sreg & 15], acc[e], 0, 0, 0);   // 4 independent chains
+        }
+    }
+    f32x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float v = (acc[0][i] + acc[1][i]) + (acc[2][i] + acc[3][i]);
+        o[i] = v + __shfl_xor(v, 32, WAVE) + bias[i];  // the two lane halves hold the two halves of the channels
+    }
+    return o;
+}
+
 template <int NT, bool HAS_RES, bool STORE>
 __global__ __launch_bounds__(256) void field_tile_kernel(FieldArgs a) {
 #ifdef CNERF_STAMPS
@@ -424,35 +465,9 @@ __global__ __launch_bounds__(256) void field_tile_kernel(FieldArgs a) {
             }
         }
 
-        // ---- head: 4 output rows padded to one 32-row tile; rows 0..3 land in registers 0..3 of half 0 --------------
+        // ---- head: 4 outputs on the 4x4x1 MFMA (16 blocks of 4 points), see pack_head_kernel -------------------------------
         {
-            f32x16 acc;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-            if (h == 0) {
-                acc[0] = bias[0];
-                acc[1] = bias[1];
-                acc[2] = bias[2];
-                acc[3] = bias[3];
-            }
-            constexpr int NG = NT * 4;
-            f32x4 ring[RING];
-#pragma unroll
-            for (int i = 0; i < RING; ++i)
-                if (i < NG) ring[i] = wp[i * 64 + lane];
-#pragma unroll
-            for (int tk = 0; tk < NT; ++tk) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int idx = tk * 4 + g;
-                    const f32x4 aw = ring[idx % RING];
-                    if (idx + RING < NG) ring[idx % RING] = wp[(idx + RING) * 64 + lane];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[e], x.v[tk][4 * g + e], acc, 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
+            const f32x4 acc = head_forward<NT>(wp, bias, x.v, lane);
             if (valid && h == 0) {
                 f32x4 o;
                 if (a.flags & CNERF_F_SIGMOID_RGB) {
@@ -581,16 +596,7 @@ __global__ __launch_bounds__(256) void field_pw_kernel(FieldArgs a) {
             bias += 3 * H;
         }
         // head
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-        if (h == 0) {
-            acc[0] = bias[0];
-            acc[1] = bias[1];
-            acc[2] = bias[2];
-            acc[3] = bias[3];
-        }
-        acc = mfma_accumulate<NT>(wp, x.v, acc, lane);
+        const f32x4 acc = head_forward<NT>(wp, bias, x.v, lane);
         if (valid && h == 0) {
             f32x4 o;
             const bool sg = a.flags & CNERF_F_SIGMOID_RGB;
@@ -828,6 +834,12 @@ __global__ void pack_head_t_kernel(const float* __restrict__ w, int H, float* __
 hipError_t launch_pack_matrix_t(const float* w, int n_rows_w, int n_cols_w, int OT, float* dst, hipStream_t stream) {
     const int total = OT * (n_rows_w / 32) * 4 * 64 * 4;
     hipLaunchKernelGGL(pack_matrix_t_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, w, n_rows_w, n_cols_w, OT, dst);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_head(const float* w, int H, float* dst, hipStream_t stream) {
+    const int total = (H / 2) * 64;
+    hipLaunchKernelGGL(pack_head_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, w, H, dst);
     return hipGetLastError();
 }
 

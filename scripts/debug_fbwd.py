@@ -32,7 +32,7 @@ def run(variant, B, n_side, S, V, H, seed=0, dtype=torch.float32):
     net.to(dev)
     fr, ph = net.film(glob.to(dev)); fr, ph = fr.detach(), ph.detach()
     fcl = ops.channel_last(fvol.to(dev))
-    cfg = ops.make_cfg(net, B, V, R, S, 30.0, 0.1, 1.0)
+    cfg = ops.make_cfg(net, B, [fcl], R, S, 30.0, 0.1, 1.0)
     packed = ops.pack_field(net, cfg); packed_t = ops.pack_field_transposed(net, cfg)
     out = ops.field_forward(net, fcl, fr, ph, pts.to(dev), fvol_is_channel_last=True)
     nl = len(spec.layers)
@@ -40,9 +40,10 @@ def run(variant, B, n_side, S, V, H, seed=0, dtype=torch.float32):
     a_feat = torch.empty(N, 32, device=dev); a_h = torch.empty(nl, N, H, device=dev); a_c = torch.empty(nl, N, H, device=dev)
     a_g = torch.empty(nl, N, H, device=dev); a_go = torch.empty(N, 4, device=dev); gfv = torch.zeros_like(fcl)
     ptd = pts.to(dev).contiguous(); upd = up.to(dev).contiguous()
-    L.check(L.lib().cnerf_field_backward(C.byref(cfg), 2, 0, B, L.ptr(fcl), L.ptr(packed), L.ptr(packed_t), L.ptr(fr), L.ptr(ph),
+    vs, gvs = ops.volumes_struct([fcl]), ops.volumes_struct([gfv])
+    L.check(L.lib().cnerf_field_backward(C.byref(cfg), 2, 0, B, C.byref(vs), L.ptr(packed), L.ptr(packed_t), L.ptr(fr), L.ptr(ph),
             L.ptr(torch.eye(4, device=dev).repeat(B, 1, 1).contiguous()), L.ptr(ptd), None, L.ptr(upd), L.ptr(out), L.ptr(a_feat), L.ptr(a_h), L.ptr(a_c),
-            L.ptr(a_g), L.ptr(a_go), L.ptr(gfv), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "fbwd")
+            L.ptr(a_g), L.ptr(a_go), C.byref(gvs), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "fbwd")
     torch.cuda.synchronize()
     gfv_cf = ops.channel_first(gfv).cpu()
     print(f"{variant} B={B} n={n} V={V} H={H}: fwd err {scaled_err(out.cpu().numpy(), out32.numpy()):.2e} | fvol grad: hip-vs-ref32 {scaled_err(gfv_cf.numpy(), g32[0].numpy()):.2e}  ref32-vs-ref64 {scaled_err(g32[0].numpy(), g64[0].numpy()):.2e}  hip-vs-ref64 {scaled_err(gfv_cf.numpy(), g64[0].numpy()):.2e}")

@@ -13,7 +13,7 @@ fvol, glob = torch.randn(B, 32, 64, 64, 64, device=dev), torch.randn(B, 256, dev
 cam = torch.eye(4, device=dev).unsqueeze(0).repeat(B, 1, 1); cam[:, 2, 3] = -1.0
 freq, phase = net.film(glob)
 fcl = ops.channel_last(fvol)
-cfg = ops.make_cfg(net, B, 64, R, S, 49.13, 0.25, 1.95, 0.0, False, True, False, "relu")   # non-hierarchical: one field launch
+cfg = ops.make_cfg(net, B, [fcl], R, S, 49.13, 0.25, 1.95, 0.0, False, True, False, "relu")   # non-hierarchical: one field launch
 packed = ops.pack_field(net, cfg)
 _, _, wsb = ops.sizes(cfg)
 ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
@@ -24,12 +24,13 @@ r = L.Rng(); r.u_strat = u.data_ptr()
 aux = L.Aux(); aux.cdf = stamps.data_ptr()
 for it in range(2):
     stamps.zero_()
-    L.check(L.lib().cnerf_render_forward(C.byref(cfg), L.ptr(fcl), L.ptr(packed), L.ptr(freq.detach()), L.ptr(phase.detach()), L.ptr(cam),
+    vs = ops.volumes_struct([fcl])
+    L.check(L.lib().cnerf_render_forward(C.byref(cfg), C.byref(vs), L.ptr(packed), L.ptr(freq.detach()), L.ptr(phase.detach()), L.ptr(cam),
                                          C.byref(r), L.ptr(px), L.ptr(dp), C.byref(aux), L.ptr(ws), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "render")
     torch.cuda.synchronize()
 st = stamps[:16].view(torch.int64)[:8].cpu().tolist()
 tiles = B * R * R * S // 32
-names = ["loop/store", "position+gather", "layer0", "hidden(all)", "head"]
+names = ["loop/store", "position+lookup+layer0 MFMA", "layer0 epilogue", "hidden(all)", "head"]
 tot = sum(st[:5])
 for n, v in zip(names, st[:5]):
     print(f"{n:18s} {v / tiles:12.0f} ticks/tile  {100.0 * v / tot:5.1f}%")
