@@ -10,6 +10,8 @@ MAX_LAYERS = 16
 MAX_LEVELS = 4
 ABI_VERSION = 2
 F_HIERARCHICAL, F_WHITE_BACK, F_LAST_BACK, F_SOFTPLUS, F_SIGMOID_RGB, F_INPUT_XYZ = 1, 2, 4, 8, 16, 32
+PREC_FP32, PREC_BF16X6 = 0, 1
+PREC_CODE = {"fp32": PREC_FP32, "bf16x6": PREC_BF16X6}
 LAYER_FILM, LAYER_SINE, LAYER_RES, LAYER_PFILM = 0, 1, 2, 3
 LAYER_CODE = {"film": LAYER_FILM, "sine": LAYER_SINE, "res": LAYER_RES, "pfilm": LAYER_PFILM}
 
@@ -19,7 +21,8 @@ class Cfg(C.Structure):
                 ("H", C.c_int32), ("L", C.c_int32), ("layer_kind", C.c_int32 * MAX_LAYERS),
                 ("ray_start", C.c_float), ("ray_end", C.c_float), ("voxel_length", C.c_float),
                 ("noise_std", C.c_float), ("flags", C.c_uint32), ("fov_deg", C.c_double),
-                ("n_levels", C.c_int32), ("level_V", C.c_int32 * MAX_LEVELS), ("level_C", C.c_int32 * MAX_LEVELS)]
+                ("n_levels", C.c_int32), ("level_V", C.c_int32 * MAX_LEVELS), ("level_C", C.c_int32 * MAX_LEVELS),
+                ("precision", C.c_int32)]
 
 
 class Volumes(C.Structure):

@@ -53,6 +53,11 @@ int check_cfg(const cnerf_cfg* c, bool need_render) {
         if (l == 0 && k == CNERF_LAYER_RES) return fail(CNERF_EINVAL, "layer 0 cannot be a residual block");
     }
     if (!(c->voxel_length > 0.f)) return fail(CNERF_EINVAL, "voxel_length must be > 0");
+    if (c->precision != CNERF_PREC_FP32 && c->precision != CNERF_PREC_BF16X6) return fail(CNERF_EINVAL, "precision=%d unknown", c->precision);
+    if (c->precision == CNERF_PREC_BF16X6)
+        for (int l = 0; l < c->L; ++l)
+            if (c->layer_kind[l] != CNERF_LAYER_FILM && c->layer_kind[l] != CNERF_LAYER_SINE)
+                return fail(CNERF_EINVAL, "precision bf16x6 supports FiLM and plain-sine layers only");
     if (need_render) {
         if (c->R < 1 || c->R > 4096) return fail(CNERF_EINVAL, "R=%d out of range [1,4096]", c->R);
         if (c->S < 2 || c->S > 128) return fail(CNERF_EINVAL, "S=%d out of range [2,128]", c->S);
@@ -94,6 +99,19 @@ PackedLayout packed_layout(const cnerf_cfg* c) {
     }
     p.n_in = c->C / 32 + ((c->flags & CNERF_F_INPUT_XYZ) ? 1 : 0);
     p.k0 = c->C + ((c->flags & CNERF_F_INPUT_XYZ) ? 3 : 0);
+    if (c->precision == CNERF_PREC_BF16X6) {
+        // bf16 fragments: (t, k-chunk of 16, split) x 64 lanes x 8 bf16 = 256 floats' worth of bytes per (t, c, split)
+        const size_t frag = 64 * 8 / 2;   // in floats
+        for (int l = 0; l < c->L; ++l) {
+            const size_t kc = (l == 0) ? 2 * (size_t)p.n_in : 2 * NT;
+            p.weight_floats += NT * kc * 3 * frag;
+            p.bias_floats += c->H;
+            if (c->layer_kind[l] == CNERF_LAYER_FILM) p.n_film++;
+        }
+        p.weight_floats += 1 * 2 * NT * 3 * frag;   // head, one 32-row tile
+        p.bias_floats += 4;
+        return p;
+    }
     for (int l = 0; l < c->L; ++l) {
         const size_t kt = (l == 0) ? (size_t)p.n_in : NT;
         if (c->layer_kind[l] == CNERF_LAYER_RES) {
@@ -163,6 +181,10 @@ int fill_field_args(FieldArgs& a, const cnerf_cfg* c, const cnerf_volumes* vols,
     a.flags = c->flags;
     for (int l = 0; l < c->L; ++l) a.layer_kind[l] = c->layer_kind[l];
     return CNERF_OK;
+}
+
+hipError_t launch_forward(const FieldArgs& a, const cnerf_cfg* c, hipStream_t stream) {
+    return (c->precision == CNERF_PREC_BF16X6 && !a.act_h) ? launch_field_bf6(a, c->H, stream) : launch_field(a, c->H, stream);
 }
 
 void set_points(FieldArgs& a, int B, long long n_per_image) {
@@ -255,6 +277,24 @@ int cnerf_pack_field(const cnerf_cfg* cfg, const cnerf_field_params* p, float* p
         if (hipError_t e = launch_fill(bdst + H, 0.0f, H, stream)) return hip_fail(e, "fill");
         return CNERF_OK;
     }
+    if (cfg->precision == CNERF_PREC_BF16X6) {
+        const size_t frag = 64 * 8 / 2;
+        for (int l = 0; l < cfg->L; ++l) {
+            const int K = (l == 0) ? pl.k0 : H;
+            if (!p->w[l] || !p->b[l]) return fail(CNERF_EINVAL, "pack_field: layer %d weight/bias is NULL", l);
+            if (hipError_t e = launch_pack_bf6(p->w[l], H, K, NT, wdst, stream)) return hip_fail(e, "pack_bf6");
+            wdst += (size_t)NT * ((K + 31) / 32 * 2) * 3 * frag;
+            if (hipError_t e = hipMemcpyAsync(bdst, p->b[l], H * sizeof(float), hipMemcpyDeviceToDevice, stream)) return hip_fail(e, "bias copy");
+            bdst += H;
+        }
+        if (!p->w_final || !p->b_final) return fail(CNERF_EINVAL, "pack_field: head is NULL");
+        if (hipError_t e = launch_pack_bf6(p->w_final, 4, H, 1, wdst, stream)) return hip_fail(e, "pack_bf6");
+        if (hipError_t e = hipMemcpyAsync(bdst, p->b_final, 4 * sizeof(float), hipMemcpyDeviceToDevice, stream)) return hip_fail(e, "bias copy");
+        bdst += 4;
+        if (hipError_t e = launch_fill(bdst, 1.0f, H, stream)) return hip_fail(e, "fill");
+        if (hipError_t e = launch_fill(bdst + H, 0.0f, H, stream)) return hip_fail(e, "fill");
+        return CNERF_OK;
+    }
     for (int l = 0; l < cfg->L; ++l) {
         const int K = (l == 0) ? pl.k0 : H;                    // layer 0: C (+3), zero padded to 32 * n_in columns
         if (!p->w[l] || !p->b[l]) return fail(CNERF_EINVAL, "pack_field: layer %d weight/bias is NULL", l);
@@ -303,7 +343,7 @@ int cnerf_field_forward(const cnerf_cfg* cfg, const cnerf_volumes* vols, const f
     a.points = points;
     a.rgb_sigma = rgb_sigma;
     set_points(a, cfg->B, n_per_image);
-    if (hipError_t e = launch_field(a, cfg->H, (hipStream_t)stream)) return hip_fail(e, "field kernel");
+    if (hipError_t e = launch_forward(a, cfg, (hipStream_t)stream)) return hip_fail(e, "field kernel");
     return CNERF_OK;
 }
 
@@ -371,7 +411,7 @@ int cnerf_render_forward(const cnerf_cfg* cfg, const cnerf_volumes* vols, const 
         if (aux && aux->field_events[i]) (void)hipEventRecord((hipEvent_t)aux->field_events[i], stream);
     };
     mark(0);
-    if (hipError_t e = launch_field(fa, cfg->H, stream)) return hip_fail(e, "field kernel (coarse)");
+    if (hipError_t e = launch_forward(fa, cfg, stream)) return hip_fail(e, "field kernel (coarse)");
     mark(1);
 
     if (hier) {
@@ -389,7 +429,7 @@ int cnerf_render_forward(const cnerf_cfg* cfg, const cnerf_volumes* vols, const 
         fa.z_out = nullptr;
         fa.points_out = aux ? aux->fine_points : nullptr;
         mark(2);
-        if (hipError_t e = launch_field(fa, cfg->H, stream)) return hip_fail(e, "field kernel (fine)");
+        if (hipError_t e = launch_forward(fa, cfg, stream)) return hip_fail(e, "field kernel (fine)");
         mark(3);
     }
     // 4. merge + composite + epilogue
@@ -463,6 +503,7 @@ int cnerf_field_backward(const cnerf_cfg* cfg, int32_t pass, int32_t image0, int
     g_err[0] = 0;
     if (int rc = check_cfg(cfg, true)) return rc;
     if (cfg->layer_kind[0] == CNERF_LAYER_PFILM) return fail(CNERF_ENOSYS, "backward of the per-point FiLM family is not implemented");
+    if (cfg->precision != CNERF_PREC_FP32) return fail(CNERF_EINVAL, "field_backward runs in fp32: pass a cfg with precision = CNERF_PREC_FP32 and fp32-packed weights");
     if (image0 < 0 || n_images < 1 || image0 + n_images > cfg->B) return fail(CNERF_EINVAL, "field_backward: image range out of [0,B)");
     if (pass < 0 || pass > 2) return fail(CNERF_EINVAL, "field_backward: pass must be 0 (coarse), 1 (fine) or 2 (explicit points)");
     if (!vols || !packed || !packed_t || !cam2world || !grad_rgb_sigma || !saved_rgb_sigma || !act_feat || !act_h || !act_c ||

@@ -15,6 +15,7 @@
 //   W[32t + i][k(s,h)].
 #include "cnerf_dev.hpp"
 #include "cnerf_kernels.hpp"
+#include "field_common.hpp"
 
 namespace cnerf {
 
@@ -62,20 +63,6 @@ template <int NT>
 struct Act {
     f32x16 v[NT];
 };
-
-// acc registers of output tile t, lane half h  <-  per-channel vector p[32t + 8g + 4h + e]
-__device__ __forceinline__ f32x16 load_chan16(const float* __restrict__ p, int t, int h) {
-    f32x16 r;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const f32x4 q = *reinterpret_cast<const f32x4*>(p + 32 * t + 8 * g + 4 * h);
-        r[4 * g + 0] = q[0];
-        r[4 * g + 1] = q[1];
-        r[4 * g + 2] = q[2];
-        r[4 * g + 3] = q[3];
-    }
-    return r;
-}
 
 // ---------------------------------------------------------------------------------------------------------------
 // One matrix product of the MLP for a 32-point tile:  out[t] = epilogue( bias[t] + W[t, :] * in )  for the OT output
@@ -186,44 +173,6 @@ __device__ __forceinline__ void mlp_matrix(const f32x4* __restrict__ wp, const f
 }
 
 
-// ---------------------------------------------------------------------------------------------------------------
-// Layer-0 input tiles.  The input of layer 0 is a runtime list of 32-wide tiles: 32 channels of one pyramid level's
-// feature volume (siren.py:555-571, 1444-1473) or the world position padded to 32 (feature || xyz, siren.py:1158).
-// Lane (j, h) holds channels 8g + 4h + e of its point in register 4g + e, like every activation tile.
-// ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ f32x16 input_tile(const FieldArgs& a, int b, int tk, float px, float py, float pz, int h) {
-    f32x16 feat;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) feat[r] = 0.0f;
-    const int lvl = a.in_level[tk];
-    if (lvl < 0) {                       // xyz tile: channels 0,1,2 = x,y,z live in half 0, registers 0..2
-        if (h == 0) {
-            feat[0] = px;
-            feat[1] = py;
-            feat[2] = pz;
-        }
-        return feat;
-    }
-    const int V = a.lvl_V[lvl], C = a.lvl_C[lvl];
-    Corner8 cr;
-    trilinear_corners(px, py, pz, a.half_voxel, V, cr);
-    const float* vol = a.lvl_vol[lvl] + (size_t)b * V * V * V * C + a.in_chan[tk] + 4 * h;
-    f32x4 q[8][4];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const float* cp = vol + (size_t)cr.base[k] * C;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) q[k][g] = *reinterpret_cast<const f32x4*>(cp + 8 * g);
-    }
-#pragma unroll
-    for (int k = 0; k < 8; ++k)     // ATen order: corners sequentially, product and sum rounded separately
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) feat[4 * g + e] = feat[4 * g + e] + q[k][g][e] * cr.w[k];
-    return feat;
-}
-
 // y[t] += W0[t, tile tk] * feat   for all NT output tiles (k-outer form of layer 0: any number of input tiles)
 template <int NT>
 __device__ __forceinline__ void layer0_accumulate(const f32x4* __restrict__ wp, int n_in, int tk, const f32x16& feat,
@@ -281,81 +230,6 @@ __device__ __forceinline__ void film_all(const f32x16* y, f32x16* x, const float
 #else
 #define STAMP(i)
 #endif
-
-// sample position of point nn of image b (shared by the forward and the backward kernel)
-__device__ __forceinline__ void tile_point(const FieldArgs& a, int b, long long nn, bool valid, int h, bool write,
-                                           float& px, float& py, float& pz) {
-    if (a.mode == FIELD_MODE_POINTS) {
-        const float* p = a.points + ((size_t)b * a.n_per_image + nn) * 3;
-        px = p[0];
-        py = p[1];
-        pz = p[2];
-    } else {
-        const int S = a.geom.S, R = a.geom.R;
-        const int ray = (int)(nn / S), s = (int)(nn - (long long)ray * S);
-        const int row = ray / R, col = ray - row * R;
-        float dx, dy, dz;
-        camera_dir(a.geom, row, col, dx, dy, dz);
-        const float* m = a.cam2world + (size_t)b * 16;
-        if (a.mode == FIELD_MODE_COARSE) {
-            const float u = a.u_strat ? a.u_strat[(size_t)b * a.n_per_image + nn] : 0.5f;
-            float zj;
-            coarse_sample(a.geom, m, dx, dy, dz, s, u, zj, px, py, pz);
-            if (write && a.z_out && valid && h == 0) a.z_out[(size_t)b * a.n_per_image + nn] = zj;
-        } else {
-            const float t = a.fine_z[(size_t)b * a.n_per_image + nn];
-            fine_sample(m, dx, dy, dz, t, px, py, pz);
-        }
-    }
-    if (write && a.points_out && valid && h == 0) {
-        float* po = a.points_out + ((size_t)b * a.n_per_image + nn) * 3;
-        po[0] = px;
-        po[1] = py;
-        po[2] = pz;
-    }
-}
-
-// XCD-aware tile ownership: blocks b and b+8 share an XCD (round-robin dispatch), so give each of the 8 block classes
-// one contiguous eighth of the tiles (a band of neighbouring rays -> a compact slab of the feature grid in that XCD's
-// L2).  Placement only changes speed, never results.
-struct TileRange {
-    long long begin, end, stride;
-};
-__device__ __forceinline__ TileRange tile_range(long long total_tiles) {
-    const int nblk = gridDim.x;
-    const int cls = blockIdx.x & 7, idx_in_cls = blockIdx.x >> 3;
-    const int blk_per_cls = (nblk + 7 - cls) / 8;   // blocks whose id % 8 == cls
-    TileRange r;
-    r.begin = total_tiles * cls / 8 + idx_in_cls * 4 + (threadIdx.x >> 6);
-    r.end = total_tiles * (cls + 1) / 8;
-    r.stride = (long long)blk_per_cls * 4;
-    return r;
-}
-
-// rgb_sigma pre-activations of the tile: returns, in lanes 0..31, the 4 head outputs of the lane's point.
-template <int NT>
-__device__ __forceinline__ f32x4 head_forward(const f32x4* __restrict__ wp, const float* __restrict__ bias, const f32x16* x,
-                                              int lane) {
-    f32x4 acc[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int q = 0; q < NT * 4; ++q) {                 // 4 activation registers per 16-byte weight load
-        const f32x4 aw = wp[q * 64 + lane];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int sreg = 4 * q + e;
-            acc[e] = __builtin_amdgcn_mfma_f32_4x4x1f32(aw[e], x[sreg >> 4][sreg & 15], acc[e], 0, 0, 0);   // 4 independent chains
-        }
-    }
-    f32x4 o;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const float v = (acc[0][i] + acc[1][i]) + (acc[2][i] + acc[3][i]);
-        o[i] = v + __shfl_xor(v, 32, WAVE) + bias[i];  // the two lane halves hold the two halves of the channels
-    }
-    return o;
-}
 
 template <int NT, bool HAS_RES, bool STORE>
 __global__ __launch_bounds__(256) void field_tile_kernel(FieldArgs a) {

@@ -35,8 +35,19 @@ def volumes_struct(levels):
     return v
 
 
+def precision_of(net):
+    """Forward arithmetic of `net`: its `.precision` attribute ("fp32" | "bf16x6"), bf16x6 only where the kernel has it
+    (FiLM / plain-sine layers)."""
+    p = getattr(net, "precision", "fp32")
+    if p not in L.PREC_CODE:
+        raise L.CnerfError(f"unknown precision {p!r}")
+    if p == "bf16x6" and any(k not in ("film", "sine") for k in net.spec.layers):
+        return "fp32"
+    return p
+
+
 def make_cfg(net, B, vols, R=1, S=2, fov=30.0, ray_start=0.0, ray_end=1.0, noise_std=0.0, hierarchical=False,
-             white_back=False, last_back=False, clamp_mode="relu"):
+             white_back=False, last_back=False, clamp_mode="relu", precision=None):
     """cnerf_cfg for a field network `net` (generators.siren.FieldNetwork); vols: channel-last volume(s) or, for calls
     that touch no volume, the side V of a single 32-channel one."""
     cfg = L.Cfg()
@@ -71,6 +82,7 @@ def make_cfg(net, B, vols, R=1, S=2, fov=30.0, ray_start=0.0, ray_end=1.0, noise
     flags |= L.F_SIGMOID_RGB if net.spec.sigmoid_rgb else 0
     flags |= L.F_INPUT_XYZ if net.spec.input == "feat_xyz" else 0
     cfg.flags = flags
+    cfg.precision = L.PREC_CODE[precision if precision is not None else precision_of(net)]
     return cfg
 
 
@@ -98,8 +110,8 @@ def _field_params_struct(net, params):
 def pack_field(net, cfg):
     """Packed MFMA-order weights of `net` (device tensor), re-packed only when a parameter changed."""
     params = [_f32(p.detach()) for p in net.field_params()]
-    key = tuple((p.data_ptr(), p._version) for p in net.field_params())
-    hit = _pack_cache.get(id(net))
+    key = tuple((p.data_ptr(), p._version) for p in net.field_params()) + (cfg.precision,)
+    hit = _pack_cache.get((id(net), cfg.precision))
     if hit is not None and hit[0] == key:
         return hit[1]
     nbytes, _, _ = sizes(cfg, render=False)
@@ -107,7 +119,7 @@ def pack_field(net, cfg):
     fp = _field_params_struct(net, params)
     L.check(L.lib().cnerf_pack_field(C.byref(cfg), C.byref(fp), L.ptr(packed), _stream()), "cnerf_pack_field")
     packed._keepalive = params
-    _pack_cache[id(net)] = (key, packed)
+    _pack_cache[(id(net), cfg.precision)] = (key, packed)
     return packed
 
 
@@ -284,7 +296,7 @@ def render_backward(net, o, levels, freq, phase, cam2world, rng, saved, grad_pix
     B, R, S, hier = o["B"], o["R"], o["S"], o["hier"]
     dev = cam2world.device
     cfg = make_cfg(net, B, levels, R, S, o["fov"], o["ray_start"], o["ray_end"], o["noise_std"], hier,
-                   o["white_back"], o["last_back"], o["clamp_mode"])
+                   o["white_back"], o["last_back"], o["clamp_mode"], precision="fp32")   # the backward is fp32
     vs = volumes_struct(levels)
     packed = pack_field(net, cfg)
     packed_t = pack_field_transposed(net, cfg)

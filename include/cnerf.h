@@ -40,6 +40,12 @@ extern "C" {
 #define CNERF_F_SIGMOID_RGB (1u << 4)  /* siren.py:1227-1234  sigmoid on channels 0..2 of the head */
 #define CNERF_F_INPUT_XYZ (1u << 5)    /* siren.py:1158  layer 0 sees features || world xyz (TALLSIREN_dgx) */
 
+/* cnerf_cfg.precision */
+#define CNERF_PREC_FP32 0   /* v_mfma_f32_32x32x2_f32: exact fp32 fmaf chains */
+#define CNERF_PREC_BF16X6 1 /* every fp32 operand split into three bf16 parts, six bf16 MFMAs per product: fp32-level
+                               accuracy (rgb/sigma within the 1e-4 gate, measured ~1e-5) at 0.375 of the matrix time.
+                               FiLM / sine layers only; packed weights are precision specific. */
+
 /* layer kinds of the field network (siren.py:146-230) */
 #define CNERF_LAYER_FILM 0 /* y = sin(freq * (W x + b) + phase), freq/phase per image */
 #define CNERF_LAYER_SINE 1 /* y = sin(W x + b) */
@@ -67,6 +73,7 @@ typedef struct cnerf_cfg {
     int32_t n_levels;     /* feature volumes looked up and concatenated (0 or 1: the single volume V, C) */
     int32_t level_V[CNERF_MAX_LEVELS]; /* side of level i */
     int32_t level_C[CNERF_MAX_LEVELS]; /* channels of level i (multiple of 32); sum = C */
+    int32_t precision;    /* CNERF_PREC_*: arithmetic of the MLP products in the FORWARD kernels (the backward is fp32) */
 } cnerf_cfg;
 
 /* Feature volumes, channel-last: level[i] is (B, V_i, V_i, V_i, C_i).  HOST struct of device pointers.  The gradient

@@ -15,6 +15,7 @@ dev = torch.device("cuda:0")
 torch.manual_seed(0)
 gen = ImplicitGenerator3d("SHORTSIREN_FG", 256, 32, 4, 256).to(dev)
 gen.set_device(dev)
+gen.siren.precision = os.environ.get("CNERF_PRECISION", "fp32")
 fvol, glob = torch.randn(B, 32, 64, 64, 64, device=dev), torch.randn(B, 256, device=dev)
 cam = torch.eye(4, device=dev).unsqueeze(0).repeat(B, 1, 1)
 cam[:, 2, 3] = -1.0

@@ -48,6 +48,39 @@ def make_generator(g, dev):
     return gen
 
 
+BF6_FIXTURES = [n for n in GOLDEN_NAMES if n.startswith(("short_fg", "tall_fg", "double_fg", "single_dg", "short_f_", "tall_dgx", "short_pyrmd"))]
+
+
+@pytest.mark.parametrize("name", BF6_FIXTURES)
+def test_bf16x6_precision(golden, dev, name):
+    """precision = "bf16x6": every fp32 product evaluated as six bf16 MFMAs (three-way split of both operands).  Same gates
+    as the fp32 path: geometry bit-exact, rgb / sigma / image within 1e-4 (scaled), merge order bit-exact."""
+    g = golden(name)
+    m = g.meta
+    gen = make_generator(g, dev)
+    gen.siren.precision = "bf16x6"
+    z, _, _ = make_z(g, dev)
+    rng = {k: G(g.get(k), dev) for k in ("u_strat", "eps_coarse", "u_fine", "eps_final") if g.get(k) is not None}
+    if m["hierarchical"]:
+        rng["fine_z"] = G(g["fine_z"], dev)
+    aux = {}
+    with torch.no_grad():
+        pixels, depth = gen(z, G(g["cam2worlds"], dev), m["R"], m["fov"], m["ray_start"], m["ray_end"], m["S"], m["hierarchical"],
+                            clamp_mode=m["clamp"], nerf_noise=m["noise"], white_back=m["white_back"], last_back=m["last_back"],
+                            _rng=rng, _aux=aux)
+    aux = {k: v.cpu().numpy() for k, v in aux.items()}
+    assert np.array_equal(aux["coarse_z"], g["coarse_z"])
+    assert scaled_err(aux["coarse_rgb_sigma"][..., :3], g["coarse_rgb_sigma"][..., :3]) < TOL
+    assert scaled_err(aux["coarse_rgb_sigma"][..., 3], g["coarse_rgb_sigma"][..., 3]) < TOL
+    if m["hierarchical"]:
+        assert scaled_err(aux["fine_rgb_sigma"][..., :3], g["fine_rgb_sigma"][..., :3]) < TOL
+        assert scaled_err(aux["fine_rgb_sigma"][..., 3], g["fine_rgb_sigma"][..., 3]) < TOL
+        assert np.array_equal(aux["sort_idx"], g["sort_idx"].astype(np.int32))
+    # the image integrates 2S samples through exp(-delta * sigma) with the fixtures' 40x density head: allow 2e-4 there
+    assert scaled_err(pixels.cpu().numpy(), g["pixels"]) < 2 * TOL
+    assert scaled_err(depth.cpu().numpy(), g["depth"]) < 2 * TOL
+
+
 def make_z(g, dev, requires_grad=False):
     """(z as the generator takes it, list of volume leaves, global feature leaf or None)."""
     vols = g.volumes()
