@@ -53,11 +53,11 @@ int check_cfg(const cnerf_cfg* c, bool need_render) {
         if (l == 0 && k == CNERF_LAYER_RES) return fail(CNERF_EINVAL, "layer 0 cannot be a residual block");
     }
     if (!(c->voxel_length > 0.f)) return fail(CNERF_EINVAL, "voxel_length must be > 0");
-    if (c->precision != CNERF_PREC_FP32 && c->precision != CNERF_PREC_BF16X6) return fail(CNERF_EINVAL, "precision=%d unknown", c->precision);
-    if (c->precision == CNERF_PREC_BF16X6)
+    if (c->precision != CNERF_PREC_FP32 && c->precision != CNERF_PREC_FP16X3) return fail(CNERF_EINVAL, "precision=%d unknown", c->precision);
+    if (c->precision == CNERF_PREC_FP16X3)
         for (int l = 0; l < c->L; ++l)
             if (c->layer_kind[l] != CNERF_LAYER_FILM && c->layer_kind[l] != CNERF_LAYER_SINE)
-                return fail(CNERF_EINVAL, "precision bf16x6 supports FiLM and plain-sine layers only");
+                return fail(CNERF_EINVAL, "precision fp16x3 supports FiLM and plain-sine layers only");
     if (need_render) {
         if (c->R < 1 || c->R > 4096) return fail(CNERF_EINVAL, "R=%d out of range [1,4096]", c->R);
         if (c->S < 2 || c->S > 128) return fail(CNERF_EINVAL, "S=%d out of range [2,128]", c->S);
@@ -99,17 +99,18 @@ PackedLayout packed_layout(const cnerf_cfg* c) {
     }
     p.n_in = c->C / 32 + ((c->flags & CNERF_F_INPUT_XYZ) ? 1 : 0);
     p.k0 = c->C + ((c->flags & CNERF_F_INPUT_XYZ) ? 3 : 0);
-    if (c->precision == CNERF_PREC_BF16X6) {
-        // bf16 fragments: (t, k-chunk of 16, split) x 64 lanes x 8 bf16 = 256 floats' worth of bytes per (t, c, split)
+    if (c->precision == CNERF_PREC_FP16X3) {
+        // fp16 fragments: (t, k-chunk of 16, part) x 64 lanes x 8 fp16 = 256 floats' worth of bytes per (t, c, part);
+        // behind the biases: 1/S of every matrix (L + 1), then the max|W| scratch slots (L + 1), padded to 4 floats
         const size_t frag = 64 * 8 / 2;   // in floats
         for (int l = 0; l < c->L; ++l) {
             const size_t kc = (l == 0) ? 2 * (size_t)p.n_in : 2 * NT;
-            p.weight_floats += NT * kc * 3 * frag;
+            p.weight_floats += NT * kc * 2 * frag;
             p.bias_floats += c->H;
             if (c->layer_kind[l] == CNERF_LAYER_FILM) p.n_film++;
         }
-        p.weight_floats += 1 * 2 * NT * 3 * frag;   // head, one 32-row tile
-        p.bias_floats += 4;
+        p.weight_floats += 1 * 2 * NT * 2 * frag;   // head, one 32-row tile
+        p.bias_floats += 4 + (2 * ((size_t)c->L + 1) + 3) / 4 * 4;
         return p;
     }
     for (int l = 0; l < c->L; ++l) {
@@ -184,7 +185,7 @@ int fill_field_args(FieldArgs& a, const cnerf_cfg* c, const cnerf_volumes* vols,
 }
 
 hipError_t launch_forward(const FieldArgs& a, const cnerf_cfg* c, hipStream_t stream) {
-    return (c->precision == CNERF_PREC_BF16X6 && !a.act_h) ? launch_field_bf6(a, c->H, stream) : launch_field(a, c->H, stream);
+    return (c->precision == CNERF_PREC_FP16X3 && !a.act_h) ? launch_field_h3(a, c->H, stream) : launch_field(a, c->H, stream);
 }
 
 void set_points(FieldArgs& a, int B, long long n_per_image) {
@@ -277,20 +278,22 @@ int cnerf_pack_field(const cnerf_cfg* cfg, const cnerf_field_params* p, float* p
         if (hipError_t e = launch_fill(bdst + H, 0.0f, H, stream)) return hip_fail(e, "fill");
         return CNERF_OK;
     }
-    if (cfg->precision == CNERF_PREC_BF16X6) {
+    if (cfg->precision == CNERF_PREC_FP16X3) {
         const size_t frag = 64 * 8 / 2;
+        float* inv_scale = packed + pl.weight_floats + (size_t)cfg->L * H + 4;   // 1/S per matrix, then the max|W| scratch
+        float* wmax = inv_scale + cfg->L + 1;
         for (int l = 0; l < cfg->L; ++l) {
             const int K = (l == 0) ? pl.k0 : H;
             if (!p->w[l] || !p->b[l]) return fail(CNERF_EINVAL, "pack_field: layer %d weight/bias is NULL", l);
-            if (hipError_t e = launch_pack_bf6(p->w[l], H, K, NT, wdst, stream)) return hip_fail(e, "pack_bf6");
-            wdst += (size_t)NT * ((K + 31) / 32 * 2) * 3 * frag;
+            if (hipError_t e = launch_pack_h3(p->w[l], H, K, NT, wdst, inv_scale + l, wmax + l, stream)) return hip_fail(e, "pack_h3");
+            wdst += (size_t)NT * ((K + 31) / 32 * 2) * 2 * frag;
             if (hipError_t e = hipMemcpyAsync(bdst, p->b[l], H * sizeof(float), hipMemcpyDeviceToDevice, stream)) return hip_fail(e, "bias copy");
             bdst += H;
         }
         if (!p->w_final || !p->b_final) return fail(CNERF_EINVAL, "pack_field: head is NULL");
-        if (hipError_t e = launch_pack_bf6(p->w_final, 4, H, 1, wdst, stream)) return hip_fail(e, "pack_bf6");
+        if (hipError_t e = launch_pack_h3(p->w_final, 4, H, 1, wdst, inv_scale + cfg->L, wmax + cfg->L, stream)) return hip_fail(e, "pack_h3");
         if (hipError_t e = hipMemcpyAsync(bdst, p->b_final, 4 * sizeof(float), hipMemcpyDeviceToDevice, stream)) return hip_fail(e, "bias copy");
-        bdst += 4;
+        bdst = packed + pl.weight_floats + pl.bias_floats;
         if (hipError_t e = launch_fill(bdst, 1.0f, H, stream)) return hip_fail(e, "fill");
         if (hipError_t e = launch_fill(bdst + H, 0.0f, H, stream)) return hip_fail(e, "fill");
         return CNERF_OK;

@@ -18,33 +18,65 @@ constexpr int WAVE = 64;
 // ---------------------------------------------------------------------------------------------------------------
 // sin(x) for |x| up to a few 1e4: two-term Cody-Waite reduction by pi (fused), odd degree-9 polynomial on
 // [-pi/2, pi/2], sign from the parity of the quotient.  Max error 1.2e-7 abs / 1.9 ulp on [-300, 300] (the
-// FiLM arguments are |freq*x+phase| < ~200).  13 VALU ops, no transcendental unit, no branches.
+// FiLM arguments are |freq*x+phase| < ~200).  No transcendental unit, no branches.
+// The quotient n = rint(x/pi) comes from the magic-number trick: t = fma(x, 1/pi, 1.5*2^23) has n in its low mantissa
+// bits (so parity = bit 0 of t) and n = t - 1.5*2^23 exactly; 12 VALU ops scalar, 17 for a PAIR of arguments on the
+// packed fp32 instructions of gfx950 (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two lanes' worth per issue slot).
 // ---------------------------------------------------------------------------------------------------------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr float SIN_MAGIC = 12582912.0f;              // 1.5 * 2^23
+constexpr float SIN_INV_PI = 0.31830987334251404f;
+constexpr float SIN_PI_HI = 3.1415927410125732f;
+constexpr float SIN_PI_LO = -8.742277657347586e-08f;
+constexpr float SIN_C9 = 2.629978780532838e-06f, SIN_C7 = -0.00019821235036943108f, SIN_C5 = 0.008333230391144753f,
+                SIN_C3 = -0.1666666567325592f;
+
 __device__ __forceinline__ float sin_pi_reduced(float x) {
-    const float n = __builtin_rintf(x * 0.31830987334251404f);
-    float r = __builtin_fmaf(-n, 3.1415927410125732f, x);
-    r = __builtin_fmaf(-n, -8.742277657347586e-08f, r);
+    const float t = __builtin_fmaf(x, SIN_INV_PI, SIN_MAGIC);
+    const float n = t - SIN_MAGIC;
+    float r = __builtin_fmaf(-n, SIN_PI_HI, x);
+    r = __builtin_fmaf(-n, SIN_PI_LO, r);
     const float s = r * r;
-    float p = 2.629978780532838e-06f;
-    p = __builtin_fmaf(p, s, -0.00019821235036943108f);
-    p = __builtin_fmaf(p, s, 0.008333230391144753f);
-    p = __builtin_fmaf(p, s, -0.1666666567325592f);
+    float p = SIN_C9;
+    p = __builtin_fmaf(p, s, SIN_C7);
+    p = __builtin_fmaf(p, s, SIN_C5);
+    p = __builtin_fmaf(p, s, SIN_C3);
     const float y = __builtin_fmaf(r * s, p, r);
-    const uint32_t flip = ((uint32_t)(int32_t)n) << 31;
-    return __uint_as_float(__float_as_uint(y) ^ flip);
+    return __uint_as_float(__float_as_uint(y) ^ (__float_as_uint(t) << 31));
+}
+
+__device__ __forceinline__ f32x2 splat2(float v) { return f32x2{v, v}; }
+
+// the same arithmetic on two arguments at once (bit-identical per element to sin_pi_reduced)
+__device__ __forceinline__ f32x2 sin_pi_reduced2(f32x2 x) {
+    const f32x2 t = __builtin_elementwise_fma(x, splat2(SIN_INV_PI), splat2(SIN_MAGIC));
+    const f32x2 n = t - splat2(SIN_MAGIC);
+    f32x2 r = __builtin_elementwise_fma(-n, splat2(SIN_PI_HI), x);
+    r = __builtin_elementwise_fma(-n, splat2(SIN_PI_LO), r);
+    const f32x2 s = r * r;
+    f32x2 p = splat2(SIN_C9);
+    p = __builtin_elementwise_fma(p, s, splat2(SIN_C7));
+    p = __builtin_elementwise_fma(p, s, splat2(SIN_C5));
+    p = __builtin_elementwise_fma(p, s, splat2(SIN_C3));
+    const f32x2 y = __builtin_elementwise_fma(r * s, p, r);
+    const u32x2 yb = __builtin_bit_cast(u32x2, y) ^ (__builtin_bit_cast(u32x2, t) << 31);
+    return __builtin_bit_cast(f32x2, yb);
 }
 
 // sin and cos of the same argument (shared reduction); cos: even degree-10 polynomial, max abs error 1.5e-7 on [-300, 300].
 // Used by the activation-storing forward of the backward pass.
 __device__ __forceinline__ void sincos_pi_reduced(float x, float& sn, float& cs) {
-    const float n = __builtin_rintf(x * 0.31830987334251404f);
-    float r = __builtin_fmaf(-n, 3.1415927410125732f, x);
-    r = __builtin_fmaf(-n, -8.742277657347586e-08f, r);
+    const float t = __builtin_fmaf(x, SIN_INV_PI, SIN_MAGIC);
+    const float n = t - SIN_MAGIC;
+    float r = __builtin_fmaf(-n, SIN_PI_HI, x);
+    r = __builtin_fmaf(-n, SIN_PI_LO, r);
     const float s = r * r;
-    float p = 2.629978780532838e-06f;
-    p = __builtin_fmaf(p, s, -0.00019821235036943108f);
-    p = __builtin_fmaf(p, s, 0.008333230391144753f);
-    p = __builtin_fmaf(p, s, -0.1666666567325592f);
+    float p = SIN_C9;
+    p = __builtin_fmaf(p, s, SIN_C7);
+    p = __builtin_fmaf(p, s, SIN_C5);
+    p = __builtin_fmaf(p, s, SIN_C3);
     const float y = __builtin_fmaf(r * s, p, r);
     float q = -2.6247781192978437e-07f;
     q = __builtin_fmaf(q, s, 2.4772387405391783e-05f);
@@ -52,7 +84,7 @@ __device__ __forceinline__ void sincos_pi_reduced(float x, float& sn, float& cs)
     q = __builtin_fmaf(q, s, 0.041666656732559204f);
     q = __builtin_fmaf(q, s, -0.5f);
     const float c = __builtin_fmaf(s, q, 1.0f);
-    const uint32_t flip = ((uint32_t)(int32_t)n) << 31;
+    const uint32_t flip = __float_as_uint(t) << 31;
     sn = __uint_as_float(__float_as_uint(y) ^ flip);
     cs = __uint_as_float(__float_as_uint(c) ^ flip);
 }

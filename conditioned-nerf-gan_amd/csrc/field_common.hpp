@@ -59,14 +59,80 @@ __device__ __forceinline__ f32x16 input_tile(const FieldArgs& a, int b, int tk, 
 }
 
 
-// sample position of point nn of image b (shared by the forward and the backward kernel)
-__device__ __forceinline__ void tile_point(const FieldArgs& a, int b, long long nn, bool valid, int h, bool write,
-                                           float& px, float& py, float& pz) {
+// The same in two steps, so that a kernel can put a barrier between the issue of the 32 loads and their first use.
+struct InputTile {
+    f32x4 q[8][4];
+    float w[8];
+    bool is_volume;
+};
+// tk must be a volume tile (in_level[tk] >= 0): every field of `it` is overwritten
+__device__ __forceinline__ void input_tile_issue_volume(const FieldArgs& a, int b, int tk, float px, float py, float pz, int h, InputTile& it) {
+    const int lvl = a.in_level[tk];
+    it.is_volume = true;
+    const int V = a.lvl_V[lvl], C = a.lvl_C[lvl];
+    Corner8 cr;
+    trilinear_corners(px, py, pz, a.half_voxel, V, cr);
+    const float* vol = a.lvl_vol[lvl] + (size_t)b * V * V * V * C + a.in_chan[tk] + 4 * h;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        it.w[k] = cr.w[k];
+        const float* cp = vol + (size_t)cr.base[k] * C;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) it.q[k][g] = *reinterpret_cast<const f32x4*>(cp + 8 * g);
+    }
+}
+__device__ __forceinline__ void input_tile_issue(const FieldArgs& a, int b, int tk, float px, float py, float pz, int h, InputTile& it) {
+    if (a.in_level[tk] >= 0) input_tile_issue_volume(a, b, tk, px, py, pz, h, it);
+    else it.is_volume = false;
+}
+__device__ __forceinline__ f32x16 input_tile_reduce(const InputTile& it, float px, float py, float pz, int h) {
+    f32x16 feat;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) feat[r] = 0.0f;
+    if (!it.is_volume) {
+        if (h == 0) {
+            feat[0] = px;
+            feat[1] = py;
+            feat[2] = pz;
+        }
+        return feat;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) feat[4 * g + e] = feat[4 * g + e] + it.q[k][g][e] * it.w[k];
+    return feat;
+}
+
+// sample position of point nn of image b, in two steps so that a kernel can issue the one dependent load (the jitter
+// draw, the resampled depth or the explicit point) long before it needs the position
+struct TileRaw {
+    float v[3];     // POINTS: x, y, z;  COARSE: v[0] = u;  FINE: v[0] = t
+};
+__device__ __forceinline__ TileRaw tile_point_fetch(const FieldArgs& a, int b, long long nn) {
+    TileRaw r;
+    r.v[0] = r.v[1] = r.v[2] = 0.0f;
+    const size_t gp = (size_t)b * a.n_per_image + nn;
     if (a.mode == FIELD_MODE_POINTS) {
-        const float* p = a.points + ((size_t)b * a.n_per_image + nn) * 3;
-        px = p[0];
-        py = p[1];
-        pz = p[2];
+        const float* p = a.points + gp * 3;
+        r.v[0] = p[0];
+        r.v[1] = p[1];
+        r.v[2] = p[2];
+    } else if (a.mode == FIELD_MODE_COARSE) {
+        r.v[0] = a.u_strat ? a.u_strat[gp] : 0.5f;
+    } else {
+        r.v[0] = a.fine_z[gp];
+    }
+    return r;
+}
+__device__ __forceinline__ void tile_point_finish(const FieldArgs& a, int b, long long nn, const TileRaw& raw, bool valid, int h, bool write,
+                                                  float& px, float& py, float& pz) {
+    if (a.mode == FIELD_MODE_POINTS) {
+        px = raw.v[0];
+        py = raw.v[1];
+        pz = raw.v[2];
     } else {
         const int S = a.geom.S, R = a.geom.R;
         const int ray = (int)(nn / S), s = (int)(nn - (long long)ray * S);
@@ -75,13 +141,11 @@ __device__ __forceinline__ void tile_point(const FieldArgs& a, int b, long long 
         camera_dir(a.geom, row, col, dx, dy, dz);
         const float* m = a.cam2world + (size_t)b * 16;
         if (a.mode == FIELD_MODE_COARSE) {
-            const float u = a.u_strat ? a.u_strat[(size_t)b * a.n_per_image + nn] : 0.5f;
             float zj;
-            coarse_sample(a.geom, m, dx, dy, dz, s, u, zj, px, py, pz);
+            coarse_sample(a.geom, m, dx, dy, dz, s, raw.v[0], zj, px, py, pz);
             if (write && a.z_out && valid && h == 0) a.z_out[(size_t)b * a.n_per_image + nn] = zj;
         } else {
-            const float t = a.fine_z[(size_t)b * a.n_per_image + nn];
-            fine_sample(m, dx, dy, dz, t, px, py, pz);
+            fine_sample(m, dx, dy, dz, raw.v[0], px, py, pz);
         }
     }
     if (write && a.points_out && valid && h == 0) {
@@ -90,6 +154,11 @@ __device__ __forceinline__ void tile_point(const FieldArgs& a, int b, long long 
         po[1] = py;
         po[2] = pz;
     }
+}
+__device__ __forceinline__ void tile_point(const FieldArgs& a, int b, long long nn, bool valid, int h, bool write,
+                                           float& px, float& py, float& pz) {
+    const TileRaw raw = tile_point_fetch(a, b, nn);
+    tile_point_finish(a, b, nn, raw, valid, h, write, px, py, pz);
 }
 
 // XCD-aware tile ownership: blocks b and b+8 share an XCD (round-robin dispatch), so give each of the 8 block classes

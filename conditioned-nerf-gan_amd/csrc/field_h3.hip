@@ -1,0 +1,543 @@
+// fp16x3 variant of the fused point pass: fp32-accurate products on the fp16 matrix pipe.
+//
+// Every fp32 operand is split into two fp16 parts a = a0 + a1 (a0 = a truncated to 11 significant bits, a1 = the
+// remainder rounded to fp16: 22 significant bits in total), weights are pre-scaled per matrix by a power of two so that
+// both parts stay in fp16's normal range, and a.w is evaluated as the three partial products a0 w1 + a1 w0 + a0 w0 on
+// v_mfma_f32_32x32x16_f16 (products of fp16 values are exact in fp32, accumulation is fp32; the dropped a1 w1 term is
+// O(2^-22)).  That is 3 x 32 matrix cycles per 16 k instead of 8 x 64 on v_mfma_f32_32x32x2_f32 (x 0.19), and half the
+// operand registers of a three-way bf16 split, which is what lets the next tile's lookups stay in flight in registers.
+// Measured against the reference (tests/test_gpu_parity.py::test_split_precision): the same 1e-4 gate as the fp32
+// kernel, errors at the fp32 noise floor (simulated on the CPU first: rgb 1.1e-5 / sigma 3.2e-5 on short_fg_small
+// against 6.7e-6 / 2.1e-5 for exact fp32 products; a single fp16 product would be ~1e-3).
+//
+// The register chaining of field_kernel.hip carries over: registers 8s..8s+7 of an accumulator tile, converted pairwise,
+// are the B fragment of k-chunk 2t+s of the next layer (k order inside the chunk: 8(j>>2) + 4h + (j&3)), and the packed
+// A fragments follow the same order (pack_h3_kernel).
+//
+// Weight units through LDS.  Per point tile the kernel consumes a flat sequence of equally sized weight units: one per
+// layer-0 input tile (its NT output tiles x 2 k-chunks), then for every hidden layer its NT output tiles (2*NT k-chunks
+// each), then the head -- each 4*NT pieces of 1 KiB (32 KiB at H = 256).  The four waves of a block walk that sequence in
+// lockstep on four point tiles of the same image: each wave copies a quarter of the NEXT unit into the idle half of a
+// double buffer with LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave instruction, no VGPRs), all four read the CURRENT
+// one with ds_read_b128 (conflict-free: lane-linear 16 B), and one s_barrier per unit both publishes the DMA'd half and
+// retires the reads of the other.  Why (scripts/ubench/bf6_loop_model.hip, one wave per SIMD on all CUs, 20 VALU per
+// k-chunk): with every wave streaming its own copy of the weights from L2 (4x the L2 -> CU traffic, ~20 TB/s aggregate)
+// a chunk of three MFMAs takes 123 ns, staged through LDS 97 ns, 65 ns for the MFMAs alone.  Biases, the per-layer
+// 2^-S factors and the image's freq / phase vectors live in LDS as well: vmcnt retires in order, so a wait for any
+// global load behind a DMA burst is a wait for the whole burst.
+#include "cnerf_dev.hpp"
+#include "cnerf_kernels.hpp"
+#include "field_common.hpp"
+
+namespace cnerf {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+struct Split2 {          // eight fp32 values as two fp16 fragments; dword d of a fragment = elements 2d (low half), 2d+1
+    u32x4 p[2];
+    __device__ __forceinline__ f16x8 frag(int k) const { return __builtin_bit_cast(f16x8, p[k]); }
+};
+
+// two fp32 -> packed fp16 pair, rounded toward zero (one v_cvt_pkrtz_f16_f32; saturates instead of overflowing)
+__device__ __forceinline__ uint32_t pk_rtz(float a, float b) { return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(a, b)); }
+
+// Two parts of two consecutive values into dword D of the two fragments.  hi = value truncated to 11 significant bits
+// (the fp32 with its 13 low mantissa bits cleared IS that fp16 value over fp16's normal range; below 2^-14 the two differ
+// by < 6e-8 absolute, nothing at the scale of activations and scaled weights), lo = remainder, again truncated.
+template <int D>
+__device__ __forceinline__ void split_pair(float v0, float v1, Split2& s) {
+    s.p[0][D] = pk_rtz(v0, v1);
+    const float r0 = v0 - __uint_as_float(__float_as_uint(v0) & 0xffffe000u);
+    const float r1 = v1 - __uint_as_float(__float_as_uint(v1) & 0xffffe000u);
+    s.p[1][D] = pk_rtz(r0, r1);
+}
+
+// layer-0 inputs (looked-up features, positions) are not bounded like sine outputs: clamp to fp16's range first
+__device__ __forceinline__ Split2 split8_clamped(const float* v) {
+    float c[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) c[i] = __builtin_amdgcn_fmed3f(v[i], -65504.0f, 65504.0f);
+    Split2 s;
+    split_pair<0>(c[0], c[1], s);
+    split_pair<1>(c[2], c[3], s);
+    split_pair<2>(c[4], c[5], s);
+    split_pair<3>(c[6], c[7], s);
+    return s;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// packing: fragment index ((t*KC + c)*2 + part)*64 + lane, 8 fp16 each:
+//   element j of lane (i = lane&31, h = lane>>5) = part_k( S * W[32t + i][16c + 8(j>>2) + 4h + (j&3)] )
+// S = 2^floor(log2(16384 / max|W|)) per matrix (on the device, no host round trip); 1/S goes to the kernel.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void absmax_kernel(const float* __restrict__ w, long long n, uint32_t* slot) {
+    float m = 0.0f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(w[i]));
+#pragma unroll
+    for (int d = WAVE / 2; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, WAVE));
+    if ((threadIdx.x & 63) == 0 && m == m) atomicMax(slot, __float_as_uint(m));     // non-negative floats order like their bits
+}
+
+__device__ __forceinline__ float pow2_scale(float wmax) {
+    if (!(wmax > 1e-30f) || !(wmax < 3e38f)) return 1.0f;
+    int e;
+    (void)frexpf(16384.0f / wmax, &e);          // 16384 / wmax = m 2^e, m in [0.5, 1)
+    e = e - 1 > 100 ? 100 : e - 1;
+    return ldexpf(1.0f, e);
+}
+
+__global__ void pack_h3_kernel(const float* __restrict__ w, int n_out, int K_real, int KC, int OT, const uint32_t* wmax_slot,
+                               float* inv_scale_slot, _Float16* __restrict__ dst) {
+    const float S = pow2_scale(__uint_as_float(*wmax_slot));
+    if (blockIdx.x == 0 && threadIdx.x == 0) *inv_scale_slot = 1.0f / S;
+    const long long total = (long long)OT * KC * 64 * 8;          // one thread per (t, c, lane, j): writes both parts
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int j = (int)(idx & 7), lane = (int)((idx >> 3) & 63);
+        const long long tc = idx >> 9;
+        const int c = (int)(tc % KC), t = (int)(tc / KC);
+        const int row = 32 * t + (lane & 31);
+        const int col = 16 * c + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3);
+        const float v = (row < n_out && col < K_real) ? w[(size_t)row * K_real + col] * S : 0.0f;
+        const _Float16 a0 = (_Float16)v;
+        const _Float16 a1 = (_Float16)(v - (float)a0);
+        const size_t base = ((size_t)tc * 2) * 64 * 8 + (size_t)lane * 8 + j;
+        dst[base] = a0;
+        dst[base + 64 * 8] = a1;
+    }
+}
+
+hipError_t launch_pack_h3(const float* w, int n_out, int K_real, int OT, void* dst, float* inv_scale_slot, float* wmax_slot,
+                          hipStream_t stream) {
+    if (hipError_t e = hipMemsetAsync(wmax_slot, 0, sizeof(float), stream)) return e;
+    const long long n = (long long)n_out * K_real;
+    long long rb = (n + 255) / 256;
+    if (rb > 256) rb = 256;
+    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)rb), dim3(256), 0, stream, w, n, (uint32_t*)wmax_slot);
+    const int KC = (K_real + 31) / 32 * 2;
+    const long long total = (long long)OT * KC * 64 * 8;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(pack_h3_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, w, n_out, K_real, KC, OT, (const uint32_t*)wmax_slot,
+                       inv_scale_slot, (_Float16*)dst);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// epilogue: bias, FiLM, sine, split
+// ---------------------------------------------------------------------------------------------------------------
+// bias / freq / phase of channels (r, r+1) of output tile t, lane half h, from LDS.  Issued one step ahead of their use:
+// an LDS read that is consumed at once stalls the wave for the full ds latency (lgkmcnt retires in order, behind the
+// A-fragment prefetches).
+struct FilmPair {
+    f32x2 fr, ph, bs;
+};
+__device__ __forceinline__ FilmPair film_pair_load(const float* lbias, const float* lfr, const float* lph, int t, int h, int r) {
+    FilmPair f;
+    const int ch = 32 * t + 8 * (r >> 2) + 4 * h + (r & 3);
+    f.bs = *reinterpret_cast<const f32x2*>(lbias + ch);
+    f.fr = *reinterpret_cast<const f32x2*>(lfr + ch);
+    f.ph = *reinterpret_cast<const f32x2*>(lph + ch);
+    return f;
+}
+
+// acc holds S * (W x) of accumulator elements r, r+1 (r even): pre = acc / S + bias in one rounding (S is a power of
+// two), FiLM with product and sum rounded separately like the reference (a plain sine layer runs with freq = 1,
+// phase = 0, which is exact -- one branch-free code path), sine, split into the fragments of the chunk pair `out2`
+// (element r of the tile is element r & 7 of chunk r >> 3).
+__device__ __forceinline__ void film_split_pair(const f32x16& acc, float inv_s, const FilmPair& f, int r, Split2* out2) {
+    float a0 = __builtin_fmaf(acc[r], inv_s, f.bs[0]), a1 = __builtin_fmaf(acc[r + 1], inv_s, f.bs[1]);
+    a0 = f.fr[0] * a0 + f.ph[0];
+    a1 = f.fr[1] * a1 + f.ph[1];
+    const float v0 = sin_pi_reduced(a0);
+    const float v1 = sin_pi_reduced(a1);
+    Split2& d = out2[r >> 3];
+    switch (r & 7) {
+        case 0: split_pair<0>(v0, v1, d); break;
+        case 2: split_pair<1>(v0, v1, d); break;
+        case 4: split_pair<2>(v0, v1, d); break;
+        default: split_pair<3>(v0, v1, d); break;
+    }
+}
+
+// whole tile at once (layer 0 and the last output tile of a layer), FiLM pairs fetched one step ahead
+__device__ __forceinline__ void film_split(const f32x16& acc, float inv_s, const float* lbias, const float* lfr, const float* lph, int t,
+                                           int h, Split2* out2) {
+    FilmPair f = film_pair_load(lbias, lfr, lph, t, h, 0);
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+        const FilmPair fcur = f;
+        if (r + 2 < 16) f = film_pair_load(lbias, lfr, lph, t, h, r + 2);
+        film_split_pair(acc, inv_s, fcur, r, out2);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// weight units
+// ---------------------------------------------------------------------------------------------------------------
+template <int NT>
+struct H3Lds {
+    static constexpr int KC = 2 * NT;
+    static constexpr int PIECES = KC * 2;              // 1-KiB pieces (64 fragments) per weight unit
+    static constexpr int FRAGS = PIECES * 64;          // f16x8 fragments per weight unit
+    static constexpr int PER_WAVE = PIECES / 4;        // pieces each wave copies
+};
+
+// One wave instruction moves 1 KiB: lane i's 16 bytes from src_lane land at lds_dst + OFF + 16 i (the instruction offset
+// applies to the global and to the LDS address alike).
+template <int OFF>
+__device__ __forceinline__ void dma_piece(const f16x8* src_lane, f16x8* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_lane,
+                                     (__attribute__((address_space(3))) void*)lds_dst, 16, OFF, 0);
+}
+
+// hidden / head unit (and the layer-0 unit of a single-input network): contiguous in the packed stream; wave w moves the
+// pieces [w*PER_WAVE, (w+1)*PER_WAVE), four per base address (instruction offsets 0, 1, 2, 3 KiB)
+template <int NT>
+__device__ __forceinline__ void dma_unit_flat(const f16x8* __restrict__ src, f16x8* lds_dst, int wave_u, int lane) {
+    constexpr int PW = H3Lds<NT>::PER_WAVE;
+    const f16x8* s0 = src + (size_t)wave_u * PW * 64 + lane;
+    f16x8* d0 = lds_dst + wave_u * PW * 64;
+#pragma unroll
+    for (int q = 0; q < (PW + 3) / 4; ++q) {
+        const f16x8* sq = s0 + q * 256;
+        f16x8* dq = d0 + q * 256;
+        if (4 * q + 0 < PW) dma_piece<0>(sq, dq);
+        if (4 * q + 1 < PW) dma_piece<1024>(sq, dq);
+        if (4 * q + 2 < PW) dma_piece<2048>(sq, dq);
+        if (4 * q + 3 < PW) dma_piece<3072>(sq, dq);
+    }
+}
+// layer-0 unit of input tile tk of a multi-input network: piece (t, c, part) comes from fragment ((t*KC0 + 2 tk + c)*2 + part)
+template <int NT>
+__device__ __forceinline__ void dma_unit_layer0(const f16x8* __restrict__ w0, int KC0, int tk, f16x8* lds_dst, int wave_u, int lane) {
+    if (KC0 == 2) return dma_unit_flat<NT>(w0, lds_dst, wave_u, lane);
+#pragma unroll 1
+    for (int i = 0; i < H3Lds<NT>::PER_WAVE; ++i) {
+        const int piece = wave_u * H3Lds<NT>::PER_WAVE + i;
+        const int k = piece & 1, tc = piece >> 1, c = tc & 1, t = tc >> 1;
+        dma_piece<0>(w0 + ((size_t)(t * KC0 + 2 * tk + c) * 2 + k) * 64 + lane, lds_dst + piece * 64);
+    }
+}
+
+#define H3_MFMA3(acc, a, xs)                                                                  \
+    do {                                                                                       \
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], (xs).frag(0), acc, 0, 0, 0);        \
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], (xs).frag(1), acc, 0, 0, 0);        \
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], (xs).frag(0), acc, 0, 0, 0);        \
+    } while (0)
+
+// acc (one 32-row output tile) += W_unit * x, A fragments from the LDS copy of the unit; the caller's functor runs once
+// per k-chunk (the pipelined epilogue of the previous output tile).  VALU_PER_MFMA sizes the interleave groups.
+template <int NT, int VALU_PER_MFMA, typename PerChunk>
+__device__ __forceinline__ f32x16 h3_tile_from_lds(const f16x8* lds_tile, const Split2* x, f32x16 acc, int lane, PerChunk per_chunk) {
+    constexpr int KC = 2 * NT;
+    constexpr int AHEAD = 2;
+    f16x8 ring[AHEAD][2];
+#pragma unroll
+    for (int i = 0; i < AHEAD; ++i)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) ring[i][k] = lds_tile[(i * 2 + k) * 64 + lane];
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+        f16x8 a[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) a[k] = ring[c % AHEAD][k];
+        if (c + AHEAD < KC) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) ring[c % AHEAD][k] = lds_tile[((c + AHEAD) * 2 + k) * 64 + lane];
+        }
+        H3_MFMA3(acc, a, x[c]);          // small terms first, the leading product last
+        per_chunk(c);
+        if (VALU_PER_MFMA > 0) {
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, VALU_PER_MFMA, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    return acc;
+}
+
+// layer-0 unit: all NT output tiles, two k-chunks each (the 32 channels of one input tile), one ring across the tiles
+template <int NT>
+__device__ __forceinline__ void h3_layer0_from_lds(const f16x8* lds_unit, const Split2* f2, f32x16* acc0, int lane) {
+    constexpr int Q = 2 * NT;
+    constexpr int AHEAD = 2;
+    f16x8 ring[AHEAD][2];
+#pragma unroll
+    for (int i = 0; i < AHEAD; ++i)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) ring[i][k] = lds_unit[(i * 2 + k) * 64 + lane];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        f16x8 a[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) a[k] = ring[q % AHEAD][k];
+        if (q + AHEAD < Q) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) ring[q % AHEAD][k] = lds_unit[((q + AHEAD) * 2 + k) * 64 + lane];
+        }
+        f32x16 acc = acc0[q >> 1];
+        H3_MFMA3(acc, a, f2[q & 1]);
+        acc0[q >> 1] = acc;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+#ifdef CNERF_STAMPS
+// Diagnostic build only: per-phase s_memtime totals summed over all tiles of all waves into a.stamps[0..7].
+#define BSTAMP(i)                                                                                    \
+    do {                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                           \
+        const unsigned long long now_ = __builtin_readcyclecounter();                                \
+        __builtin_amdgcn_sched_barrier(0);                                                           \
+        st_[i] += now_ - last_;                                                                      \
+        last_ = now_;                                                                                \
+    } while (0)
+#else
+#define BSTAMP(i)
+#endif
+
+// the point a wave works on: group g of 4 consecutive tiles of one image, tile `wave` of the group
+struct TilePoint {
+    int b;
+    long long nn;      // point inside the image (clamped to the last one for idle waves / padded lanes)
+    bool valid;
+};
+__device__ __forceinline__ TilePoint tile_of_group(const FieldArgs& a, long long g, long long G, int wave, int j) {
+    TilePoint p;
+    p.b = (int)(g / G);
+    const long long n = ((g - (long long)p.b * G) * 4 + wave) * 32 + j;
+    p.valid = n < a.n_per_image;
+    p.nn = p.valid ? n : (a.n_per_image - 1);
+    return p;
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void field_h3_kernel(FieldArgs a) {
+#ifdef CNERF_STAMPS
+    unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long last_ = __builtin_readcyclecounter();
+#endif
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int UNIT_FR = H3Lds<NT>::FRAGS;
+    constexpr int H = NT * 32;
+    constexpr int KCH = 2 * NT;
+    constexpr size_t FR = 64;
+    f16x8* lds = reinterpret_cast<f16x8*>(smem);                                    // two weight units
+    float* lds_bias = reinterpret_cast<float*>(smem + 2 * (size_t)UNIT_FR * 16);    // biases, head bias, 1/S per matrix, ones, zeros
+    const float* lds_ones = lds_bias + a.bias_floats;
+    const float* lds_zeros = lds_ones + H;
+    float* lds_freq = lds_bias + a.bias_floats + 2 * H;                             // FiLM vectors of the block's image
+    float* lds_phase = lds_freq + a.film_stride;
+    const float* lds_inv_s = lds_bias + (size_t)a.L * H + 4;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int j = lane & 31, h = lane >> 5;
+
+    // Work units are groups of 4 consecutive tiles of ONE image (so the block shares freq / phase); the four waves run in
+    // lockstep on the tiles of a group.  XCD-aware ownership as in tile_range(): block class c owns a contiguous eighth.
+    const long long G = (a.tiles_per_image + 3) / 4;
+    const long long total_groups = (a.total_tiles / a.tiles_per_image) * G;
+    const int nblk = gridDim.x;
+    const int cls = blockIdx.x & 7, idx_in_cls = blockIdx.x >> 3;
+    const int blk_per_cls = (nblk + 7 - cls) / 8;
+    const long long g_begin = total_groups * cls / 8 + idx_in_cls, g_end = total_groups * (cls + 1) / 8;
+
+    const int KC0 = 2 * a.n_in;
+    const f16x8* w_layer0 = reinterpret_cast<const f16x8*>(a.packed);
+    const f16x8* w_seq = w_layer0 + (size_t)NT * KC0 * 2 * FR;       // hidden unit 0 of the flat sequence
+    int cur = 0;                                                     // LDS half holding the current weight unit
+    int staged_b = -1;                                               // image whose FiLM vectors are in LDS
+    if (g_begin >= g_end) return;                                    // block-uniform
+
+    // prologue: biases and scales into LDS, weight unit 0 (layer 0, input tile 0) into half 0 (the first barrier publishes
+    // both); position and lookups of the first tile
+    for (int i = threadIdx.x; i < a.bias_floats + 2 * H; i += 256) lds_bias[i] = a.bias[i];
+    dma_unit_layer0<NT>(w_layer0, KC0, 0, lds, wave_u, lane);
+    TilePoint tp = tile_of_group(a, g_begin, G, wave, j);
+    float px, py, pz;
+    tile_point(a, tp.b, tp.nn, tp.valid, h, true, px, py, pz);
+    InputTile it;
+    input_tile_issue_volume(a, tp.b, 0, px, py, pz, h, it);      // input tile 0 is a volume tile (checked by the launcher)
+
+    for (long long g = g_begin; g < g_end; g += blk_per_cls) {
+        const int b = tp.b;
+        const long long nn = tp.nn;
+        const bool valid = tp.valid;
+        BSTAMP(0);
+        if (b != staged_b && a.freq) {                              // block-uniform
+            __syncthreads();                                        // nobody still reads the previous image's vectors
+            for (int i = threadIdx.x; i < a.film_stride; i += 256) {
+                lds_freq[i] = a.freq[(size_t)b * a.film_stride + i];
+                lds_phase[i] = a.phase[(size_t)b * a.film_stride + i];
+            }
+            staged_b = b;                                           // published by the unit barrier below
+        }
+        // raw sample coordinate of the NEXT tile: one load now, consumed behind the head's barrier
+        const bool has_next = g + blk_per_cls < g_end;
+        const TilePoint tn = tile_of_group(a, has_next ? g + blk_per_cls : g, G, wave, j);
+        const TileRaw raw_next = tile_point_fetch(a, tn.b, tn.nn);
+        BSTAMP(1);
+
+        const float* bias = lds_bias;
+        const float* lfr = lds_freq;
+        const float* lph = lds_phase;
+
+        Split2 x[KCH], y[KCH];
+        // ---- layer 0: one weight unit per input tile ------------------------------------------------------------------
+        {
+            f32x16 acc0[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc0[t][r] = 0.0f;
+            for (int tk = 0; tk < a.n_in; ++tk) {
+#ifdef CNERF_H3_NOPREFETCH
+                input_tile_issue(a, b, tk, px, py, pz, h, it);
+#else
+                if (tk > 0) input_tile_issue(a, b, tk, px, py, pz, h, it);   // tile 0 was issued during the previous head
+#endif
+                __syncthreads();                                    // unit `tk` has landed; the other half is free
+                if (tk + 1 < a.n_in) dma_unit_layer0<NT>(w_layer0, KC0, tk + 1, lds + (cur ^ 1) * UNIT_FR, wave_u, lane);
+                else dma_unit_flat<NT>(w_seq, lds + (cur ^ 1) * UNIT_FR, wave_u, lane);
+                const f32x16 feat = input_tile_reduce(it, px, py, pz, h);
+                float fv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) fv[r] = feat[r];
+                Split2 f2[2];
+                f2[0] = split8_clamped(fv);
+                f2[1] = split8_clamped(fv + 8);
+                h3_layer0_from_lds<NT>(lds + cur * UNIT_FR, f2, acc0, lane);
+                cur ^= 1;
+            }
+            BSTAMP(2);
+            const bool film = a.layer_kind[0] == CNERF_LAYER_FILM;
+            const float inv_s = lds_inv_s[0];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) film_split(acc0[t], inv_s, bias, film ? lfr : lds_ones, film ? lph : lds_zeros, t, h, &x[2 * t]);
+            bias += H;
+            if (film) {
+                lfr += H;
+                lph += H;
+            }
+        }
+        BSTAMP(3);
+        // ---- hidden layers: NT weight units each ----------------------------------------------------------------------
+        int seq = 0;
+        for (int l = 1; l < a.L; ++l) {
+            const bool film = a.layer_kind[l] == CNERF_LAYER_FILM;
+            const float* fr_l = film ? lfr : lds_ones;
+            const float* ph_l = film ? lph : lds_zeros;
+            const float inv_s = lds_inv_s[l];
+            f32x16 acc_prev;
+            FilmPair fp;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                __syncthreads();                               // weight unit `seq` has landed; the other half is free
+                dma_unit_flat<NT>(w_seq + (size_t)(seq + 1) * UNIT_FR, lds + (cur ^ 1) * UNIT_FR, wave_u, lane);
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+                acc = h3_tile_from_lds<NT, 7>(lds + cur * UNIT_FR, x, acc, lane, [&](int c) {
+                    if (t > 0 && c < 16) {                     // epilogue of tile t-1, one pair of elements per two chunks
+                        if (!(c & 1)) fp = film_pair_load(bias, fr_l, ph_l, t - 1, h, c);
+                        else film_split_pair(acc_prev, inv_s, fp, c - 1, &y[2 * (t - 1)]);
+                    }
+                });
+                if (t > 0 && KCH < 16) {                       // narrow networks: the rest of tile t-1's elements
+#pragma unroll
+                    for (int r = KCH; r < 16; r += 2)
+                        film_split_pair(acc_prev, inv_s, film_pair_load(bias, fr_l, ph_l, t - 1, h, r), r, &y[2 * (t - 1)]);
+                }
+                acc_prev = acc;
+                cur ^= 1;
+                ++seq;
+            }
+            film_split(acc_prev, inv_s, bias, fr_l, ph_l, NT - 1, h, &y[2 * (NT - 1)]);
+#pragma unroll
+            for (int c = 0; c < KCH; ++c) x[c] = y[c];
+            bias += H;
+            if (film) {
+                lfr += H;
+                lph += H;
+            }
+        }
+        BSTAMP(4);
+        // ---- head (last unit of the sequence).  Behind its barrier: layer-0 unit 0 streams in for the next group, the
+        // next tile's position is finished and its 32 lookups are issued -- they fly under the head's MFMAs.
+        {
+            __syncthreads();
+            if (has_next) dma_unit_layer0<NT>(w_layer0, KC0, 0, lds + (cur ^ 1) * UNIT_FR, wave_u, lane);
+            float nx, ny, nz;                                   // without a next group: this tile again (harmless, keeps `it` dead above)
+            tile_point_finish(a, tn.b, tn.nn, raw_next, tn.valid, h, has_next, nx, ny, nz);
+#ifndef CNERF_H3_NOPREFETCH
+            input_tile_issue_volume(a, tn.b, 0, nx, ny, nz, h, it);
+#endif
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+            acc = h3_tile_from_lds<NT, 0>(lds + cur * UNIT_FR, x, acc, lane, [](int) {});
+            cur ^= 1;
+            if (valid && h == 0) {
+                const f32x4 hb = *reinterpret_cast<const f32x4*>(bias);
+                const float inv_s = lds_inv_s[a.L];
+                f32x4 o;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = __builtin_fmaf(acc[i], inv_s, hb[i]);
+                if (a.flags & CNERF_F_SIGMOID_RGB) {
+                    o[0] = sigmoidf_(o[0]);
+                    o[1] = sigmoidf_(o[1]);
+                    o[2] = sigmoidf_(o[2]);
+                }
+                *reinterpret_cast<f32x4*>(a.rgb_sigma + ((size_t)b * a.n_per_image + nn) * 4) = o;
+            }
+            px = nx;
+            py = ny;
+            pz = nz;
+            tp = tn;
+        }
+        BSTAMP(5);
+    }
+#ifdef CNERF_STAMPS
+    if (a.stamps && lane == 0)
+        for (int i = 0; i < 8; ++i) atomicAdd(a.stamps + i, st_[i]);
+#endif
+}
+
+template <int NT>
+static hipError_t launch_h3_nt(const FieldArgs& a, hipStream_t stream) {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+    // 64 KiB of weight units at H = 256, biases + scales, freq / phase of one image
+    const size_t lds_bytes = 2 * (size_t)H3Lds<NT>::FRAGS * 16 + ((size_t)a.bias_floats + 2 * NT * 32 + 2 * (size_t)a.film_stride) * 4;
+    static bool attr_set = false;
+    if (!attr_set) {     // room for the deepest network the ABI admits
+        const int max_lds = 2 * H3Lds<NT>::FRAGS * 16 + (3 * CNERF_MAX_LAYERS * NT * 32 + 2 * NT * 32 + 4 + 2 * (CNERF_MAX_LAYERS + 1) + 4) * 4;
+        if (hipError_t e = hipFuncSetAttribute((const void*)field_h3_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds)) return e;
+        attr_set = true;
+    }
+    const long long want = (a.total_tiles / a.tiles_per_image) * ((a.tiles_per_image + 3) / 4), cap = (long long)cus;
+    int blocks = (int)(want < cap ? want : cap);
+    if (blocks < 8) blocks = 8;
+    blocks = (blocks + 7) / 8 * 8;
+    hipLaunchKernelGGL(field_h3_kernel<NT>, dim3(blocks), dim3(256), lds_bytes, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_field_h3(const FieldArgs& a, int H, hipStream_t stream) {
+    if (a.n_in < 1 || a.in_level[0] < 0) return hipErrorInvalidValue;      // the cross-tile lookup prefetch assumes a volume tile first
+    switch (H / 32) {
+        case 2: return launch_h3_nt<2>(a, stream);
+        case 4: return launch_h3_nt<4>(a, stream);
+        case 8: return launch_h3_nt<8>(a, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace cnerf

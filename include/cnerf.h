@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define CNERF_ABI_VERSION 2
+#define CNERF_ABI_VERSION 3
 
 #define CNERF_OK 0
 #define CNERF_EINVAL (-22)  /* bad argument / unsupported shape (message via cnerf_last_error) */
@@ -42,9 +42,9 @@ extern "C" {
 
 /* cnerf_cfg.precision */
 #define CNERF_PREC_FP32 0   /* v_mfma_f32_32x32x2_f32: exact fp32 fmaf chains */
-#define CNERF_PREC_BF16X6 1 /* every fp32 operand split into three bf16 parts, six bf16 MFMAs per product: fp32-level
-                               accuracy (rgb/sigma within the 1e-4 gate, measured ~1e-5) at 0.375 of the matrix time.
-                               FiLM / sine layers only; packed weights are precision specific. */
+#define CNERF_PREC_FP16X3 2 /* every fp32 operand split into two fp16 parts (22 significant bits), three fp16 MFMAs per product
+                             * with fp32 accumulation, weights pre-scaled per matrix by a power of two: fp32-level accuracy
+                             * (same parity gate) at 3/16 of the fp32 matrix time; forward only, FiLM / sine layers */
 
 /* layer kinds of the field network (siren.py:146-230) */
 #define CNERF_LAYER_FILM 0 /* y = sin(freq * (W x + b) + phase), freq/phase per image */

@@ -6,13 +6,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 from conftest import Golden, GOLDEN_NAMES, scaled_err
-from test_gpu_parity import make_generator, make_z, G, BF6_FIXTURES
+from test_gpu_parity import make_generator, make_z, G, SPLIT_FIXTURES
 dev = torch.device("cuda:0")
 print("| fixture | variant | shape BxRxRxS | precision | points | z | feat | rgb coarse | sigma coarse | rgb fine | sigma fine | sort_idx | inds equal (free-running) | pixels | depth |")
 print("|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|")
 for name in GOLDEN_NAMES:
     g = Golden(name); m = g.meta
-    for prec in (["fp32", "bf16x6"] if name in BF6_FIXTURES else ["fp32"]):
+    for prec in (["fp32", "fp16x3"] if name in SPLIT_FIXTURES else ["fp32"]):
         gen = make_generator(g, dev); gen.siren.precision = prec
         z, _, _ = make_z(g, dev)
         rng = {k: G(g.get(k), dev) for k in ("u_strat", "eps_coarse", "u_fine", "eps_final") if g.get(k) is not None}

@@ -9,6 +9,7 @@ dev = torch.device("cuda:0"); torch.manual_seed(0)
 B, R, S = 2, 128, 64
 gen = ImplicitGenerator3d("SHORTSIREN_FG", 256, 32, 4, 256).to(dev); gen.set_device(dev)
 net = gen.siren
+net.precision = os.environ.get("CNERF_PRECISION", "fp32")
 fvol, glob = torch.randn(B, 32, 64, 64, 64, device=dev), torch.randn(B, 256, device=dev)
 cam = torch.eye(4, device=dev).unsqueeze(0).repeat(B, 1, 1); cam[:, 2, 3] = -1.0
 freq, phase = net.film(glob)
@@ -30,8 +31,11 @@ for it in range(2):
     torch.cuda.synchronize()
 st = stamps[:16].view(torch.int64)[:8].cpu().tolist()
 tiles = B * R * R * S // 32
-names = ["loop/store", "position+lookup+layer0 MFMA", "layer0 epilogue", "hidden(all)", "head"]
-tot = sum(st[:5])
-for n, v in zip(names, st[:5]):
+if net.precision == "fp16x3":
+    names = ["loop", "position (issue)", "lookup+layer0 MFMA", "layer0 epilogue", "hidden(all)", "head+store"]
+else:
+    names = ["loop/store", "position+lookup+layer0 MFMA", "layer0 epilogue", "hidden(all)", "head"]
+tot = sum(st[:len(names)])
+for n, v in zip(names, st[:len(names)]):
     print(f"{n:18s} {v / tiles:12.0f} ticks/tile  {100.0 * v / tot:5.1f}%")
 print("total ticks/tile", tot / tiles, "(s_memtime ticks at 100 MHz => x ~23 for shader cycles)")

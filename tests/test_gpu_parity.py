@@ -48,17 +48,17 @@ def make_generator(g, dev):
     return gen
 
 
-BF6_FIXTURES = [n for n in GOLDEN_NAMES if n.startswith(("short_fg", "tall_fg", "double_fg", "single_dg", "short_f_", "tall_dgx", "short_pyrmd"))]
+SPLIT_FIXTURES = [n for n in GOLDEN_NAMES if n.startswith(("short_fg", "tall_fg", "double_fg", "single_dg", "short_f_", "tall_dgx", "short_pyrmd"))]
 
 
-@pytest.mark.parametrize("name", BF6_FIXTURES)
-def test_bf16x6_precision(golden, dev, name):
-    """precision = "bf16x6": every fp32 product evaluated as six bf16 MFMAs (three-way split of both operands).  Same gates
+@pytest.mark.parametrize("name", SPLIT_FIXTURES)
+def test_split_precision(golden, dev, name):
+    """precision = "fp16x3": every fp32 product evaluated as three fp16 MFMAs (two-way split of both operands).  Same gates
     as the fp32 path: geometry bit-exact, rgb / sigma / image within 1e-4 (scaled), merge order bit-exact."""
     g = golden(name)
     m = g.meta
     gen = make_generator(g, dev)
-    gen.siren.precision = "bf16x6"
+    gen.siren.precision = "fp16x3"
     z, _, _ = make_z(g, dev)
     rng = {k: G(g.get(k), dev) for k in ("u_strat", "eps_coarse", "u_fine", "eps_final") if g.get(k) is not None}
     if m["hierarchical"]:
