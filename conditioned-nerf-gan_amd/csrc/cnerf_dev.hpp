@@ -65,6 +65,27 @@ __device__ __forceinline__ f32x2 sin_pi_reduced2(f32x2 x) {
     return __builtin_bit_cast(f32x2, yb);
 }
 
+// sin(x) on the transcendental unit: exact two-term Cody-Waite reduction by 2 pi (so the argument of v_sin_f32, which
+// takes revolutions, is in [-0.5, 0.5] with full relative accuracy), then v_sin_f32.  Measured on gfx950 over [-300, 300]
+// (scripts/ubench/vsin_accuracy.hip): max abs error 3.8e-7, rms 7.5e-8 -- three times the polynomial's maximum, five VALU
+// ops and one transcendental instead of twelve VALU ops.  Used by the split-precision kernel.
+__device__ __forceinline__ float sin_2pi_reduced_hw(float x) {
+    const float t = __builtin_fmaf(x, 0.15915494309189535f, SIN_MAGIC);
+    const float n = t - SIN_MAGIC;
+    float r = __builtin_fmaf(-n, 6.2831854820251465f, x);
+    r = __builtin_fmaf(-n, -1.7484555314695172e-07f, r);
+    return __builtin_amdgcn_sinf(r * 0.15915494309189535f);
+}
+
+__device__ __forceinline__ f32x2 sin_2pi_reduced_hw2(f32x2 x) {     // two arguments, reduction on the packed fp32 ops
+    const f32x2 t = __builtin_elementwise_fma(x, splat2(0.15915494309189535f), splat2(SIN_MAGIC));
+    const f32x2 n = t - splat2(SIN_MAGIC);
+    f32x2 r = __builtin_elementwise_fma(-n, splat2(6.2831854820251465f), x);
+    r = __builtin_elementwise_fma(-n, splat2(-1.7484555314695172e-07f), r);
+    r = r * splat2(0.15915494309189535f);
+    return f32x2{__builtin_amdgcn_sinf(r[0]), __builtin_amdgcn_sinf(r[1])};
+}
+
 // sin and cos of the same argument (shared reduction); cos: even degree-10 polynomial, max abs error 1.5e-7 on [-300, 300].
 // Used by the activation-storing forward of the backward pass.
 __device__ __forceinline__ void sincos_pi_reduced(float x, float& sn, float& cs) {

@@ -106,6 +106,46 @@ __device__ __forceinline__ f32x16 input_tile_reduce(const InputTile& it, float p
     return feat;
 }
 
+// LDS-DMA form of the lookups of a volume tile (in_level[tk] >= 0): 32 wave instructions park the 8 corner lines of every
+// point of the tile in the wave's own 32 KiB of LDS -- piece (k, g) at lds_wave + (4k + g) * 64 float4, lane-linear -- with
+// no VGPRs and no wait, so they can be issued a whole tile ahead.  input_tile_from_lds() finishes the job: it waits for
+// the wave's outstanding loads, recomputes the corner weights from the position and accumulates in ATen's order.
+__device__ __forceinline__ void input_tile_dma(const FieldArgs& a, int b, int tk, float px, float py, float pz, int h, f32x4* lds_wave) {
+    const int lvl = a.in_level[tk];
+    const int V = a.lvl_V[lvl], C = a.lvl_C[lvl];
+    Corner8 cr;
+    trilinear_corners(px, py, pz, a.half_voxel, V, cr);
+    const float* vol = a.lvl_vol[lvl] + (size_t)b * V * V * V * C + a.in_chan[tk] + 4 * h;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float* cp = vol + (size_t)cr.base[k] * C;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(cp + 8 * g),
+                                             (__attribute__((address_space(3))) void*)(lds_wave + (4 * k + g) * 64), 16, 0, 0);
+    }
+}
+__device__ __forceinline__ f32x16 input_tile_from_lds(const FieldArgs& a, int tk, float px, float py, float pz, int h, const f32x4* lds_wave,
+                                                      int lane) {
+    const int lvl = a.in_level[tk];
+    Corner8 cr;
+    trilinear_corners(px, py, pz, a.half_voxel, a.lvl_V[lvl], cr);
+    __builtin_amdgcn_s_waitcnt(0x0F70);                       // vmcnt(0): the DMA of this tile has landed
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    f32x16 feat;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) feat[r] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)     // ATen order: corners sequentially, product and sum rounded separately
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 q = lds_wave[(4 * k + g) * 64 + lane];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) feat[4 * g + e] = feat[4 * g + e] + q[e] * cr.w[k];
+        }
+    return feat;
+}
+
 // sample position of point nn of image b, in two steps so that a kernel can issue the one dependent load (the jitter
 // draw, the resampled depth or the explicit point) long before it needs the position
 struct TileRaw {

@@ -29,6 +29,13 @@
 #include "cnerf_kernels.hpp"
 #include "field_common.hpp"
 
+#ifndef CNERF_H3_PACKED_MATH
+#define CNERF_H3_PACKED_MATH 0
+#endif
+#ifndef CNERF_H3_HW_SIN
+#define CNERF_H3_HW_SIN 1
+#endif
+
 namespace cnerf {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -146,11 +153,29 @@ __device__ __forceinline__ FilmPair film_pair_load(const float* lbias, const flo
 // phase = 0, which is exact -- one branch-free code path), sine, split into the fragments of the chunk pair `out2`
 // (element r of the tile is element r & 7 of chunk r >> 3).
 __device__ __forceinline__ void film_split_pair(const f32x16& acc, float inv_s, const FilmPair& f, int r, Split2* out2) {
+#if CNERF_H3_HW_SIN && CNERF_H3_PACKED_MATH
+    f32x2 pre = __builtin_elementwise_fma(f32x2{acc[r], acc[r + 1]}, splat2(inv_s), f.bs);
+    pre = f.fr * pre + f.ph;
+    const f32x2 v = sin_2pi_reduced_hw2(pre);
+    const float v0 = v[0], v1 = v[1];
+#elif CNERF_H3_HW_SIN
+    float a0 = __builtin_fmaf(acc[r], inv_s, f.bs[0]), a1 = __builtin_fmaf(acc[r + 1], inv_s, f.bs[1]);
+    a0 = f.fr[0] * a0 + f.ph[0];
+    a1 = f.fr[1] * a1 + f.ph[1];
+    const float v0 = sin_2pi_reduced_hw(a0);
+    const float v1 = sin_2pi_reduced_hw(a1);
+#elif CNERF_H3_PACKED_MATH
+    f32x2 pre = __builtin_elementwise_fma(f32x2{acc[r], acc[r + 1]}, splat2(inv_s), f.bs);
+    pre = f.fr * pre + f.ph;
+    const f32x2 v = sin_pi_reduced2(pre);
+    const float v0 = v[0], v1 = v[1];
+#else
     float a0 = __builtin_fmaf(acc[r], inv_s, f.bs[0]), a1 = __builtin_fmaf(acc[r + 1], inv_s, f.bs[1]);
     a0 = f.fr[0] * a0 + f.ph[0];
     a1 = f.fr[1] * a1 + f.ph[1];
     const float v0 = sin_pi_reduced(a0);
     const float v1 = sin_pi_reduced(a1);
+#endif
     Split2& d = out2[r >> 3];
     switch (r & 7) {
         case 0: split_pair<0>(v0, v1, d); break;

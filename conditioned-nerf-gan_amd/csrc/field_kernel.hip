@@ -76,6 +76,10 @@ struct Act {
 #endif
 constexpr int RING = CNERF_RING;
 
+#ifndef CNERF_F32_HW_SIN
+#define CNERF_F32_HW_SIN 0
+#endif
+
 // epilogue kinds
 enum { EPI_FILM = 0, EPI_FILM_RES = 1 };
 
@@ -88,7 +92,11 @@ __device__ __forceinline__ float epilogue_one(float acc, float res, float fr, fl
         sincos_pi_reduced(fr * pre + ph, sn, cs);
         return sn;
     }
+#if CNERF_F32_HW_SIN
+    return sin_2pi_reduced_hw(fr * pre + ph);
+#else
     return sin_pi_reduced(fr * pre + ph);
+#endif
 }
 
 // row-major activation store of one output tile: lane (j,h) owns channels 32t + 8g + 4h + e of its point
@@ -231,6 +239,14 @@ __device__ __forceinline__ void film_all(const f32x16* y, f32x16* x, const float
 #define STAMP(i)
 #endif
 
+// Measured on one MI355X (bench.py, batch 8): parking the next tile's lookups in LDS by DMA removes 7.4 k cycles of wait
+// from layer 0 but the 32 scattered global_load_lds instructions cost 8.6 k cycles to issue in the head (~200 cycles each:
+// M0 rewrite + 32 distinct lines per instruction), a net loss of 0.5 %; only the one-tile-ahead fetch of the raw sample
+// coordinate is kept by default.
+#ifndef CNERF_F32_LOOKUP_DMA
+#define CNERF_F32_LOOKUP_DMA 0
+#endif
+
 template <int NT, bool HAS_RES, bool STORE>
 __global__ __launch_bounds__(256) void field_tile_kernel(FieldArgs a) {
 #ifdef CNERF_STAMPS
@@ -242,17 +258,37 @@ __global__ __launch_bounds__(256) void field_tile_kernel(FieldArgs a) {
     constexpr int H = NT * 32;
     constexpr size_t TILE4 = 4 * 64;   // float4 per (t, tk) pair
 
-    const TileRange tr = tile_range(a.total_tiles);
-    for (long long tile = tr.begin; tile < tr.end; tile += tr.stride) {
-        const int b = (int)(tile / a.tiles_per_image);
-        const long long n = (tile - (long long)b * a.tiles_per_image) * 32 + j;  // point index inside image b
-        const bool valid = n < a.n_per_image;
-        const long long nn = valid ? n : (a.n_per_image - 1);                     // padded lanes recompute the last point
+    // Cross-tile prefetch (wide networks: one block per CU anyway): the lookups of a tile's first input tile are issued as
+    // LDS-DMA during the previous tile's head, the raw sample coordinate one tile earlier still.
+    constexpr bool PF = CNERF_F32_LOOKUP_DMA && NT >= 4;
+    extern __shared__ __attribute__((aligned(16))) char smem_q[];
+    f32x4* lds_wave = reinterpret_cast<f32x4*>(smem_q) + (threadIdx.x >> 6) * (32 * 64);     // 32 KiB per wave
 
-        STAMP(0);   // loop overhead / previous store
-        // ---- sample position -------------------------------------------------------------------------------------
-        float px, py, pz;
+    const TileRange tr = tile_range(a.total_tiles);
+    auto point_of = [&](long long tile, int& b_, long long& nn_, bool& valid_) {
+        b_ = (int)(tile / a.tiles_per_image);
+        const long long n = (tile - (long long)b_ * a.tiles_per_image) * 32 + j;  // point index inside image b
+        valid_ = n < a.n_per_image;
+        nn_ = valid_ ? n : (a.n_per_image - 1);                                     // padded lanes recompute the last point
+    };
+    int b = 0;
+    long long nn = 0;
+    bool valid = false;
+    float px = 0.f, py = 0.f, pz = 0.f;
+    if (tr.begin < tr.end) {
+        point_of(tr.begin, b, nn, valid);
         tile_point(a, b, nn, valid, h, true, px, py, pz);
+        if (PF) input_tile_dma(a, b, 0, px, py, pz, h, lds_wave);
+    }
+    for (long long tile = tr.begin; tile < tr.end; tile += tr.stride) {
+        STAMP(0);   // loop overhead / previous store
+        // raw sample coordinate of the next tile of this wave (this tile again at the end of the range)
+        const bool has_next = tile + tr.stride < tr.end;
+        int nb;
+        long long nnn;
+        bool nvalid;
+        point_of(has_next ? tile + tr.stride : tile, nb, nnn, nvalid);
+        const TileRaw raw_next = tile_point_fetch(a, nb, nnn);
 
         // ---- layer 0: lookups feed the matrix pipe tile by tile ---------------------------------------------------------
         // A plain sine layer is a FiLM layer with freq = 1, phase = 0 (1*x and +0 are exact): one code path.
@@ -270,7 +306,7 @@ __global__ __launch_bounds__(256) void field_tile_kernel(FieldArgs a) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) y.v[t] = load_chan16(bias, t, h);
         for (int tk = 0; tk < a.n_in; ++tk) {
-            const f32x16 feat = input_tile(a, b, tk, px, py, pz, h);
+            const f32x16 feat = (PF && tk == 0) ? input_tile_from_lds(a, 0, px, py, pz, h, lds_wave, lane) : input_tile(a, b, tk, px, py, pz, h);
             if (STORE) {
                 float* fo = a.act_feat + gpt * (32 * a.n_in) + 32 * tk + 4 * h;
 #pragma unroll
@@ -339,6 +375,11 @@ __global__ __launch_bounds__(256) void field_tile_kernel(FieldArgs a) {
             }
         }
 
+        // ---- next tile: finish its position, send its lookups off; they land under the head and the loop overhead ----------
+        float nx, ny, nz;
+        tile_point_finish(a, nb, nnn, raw_next, nvalid, h, has_next, nx, ny, nz);
+        if (PF) input_tile_dma(a, nb, 0, nx, ny, nz, h, lds_wave);
+
         // ---- head: 4 outputs on the 4x4x1 MFMA (16 blocks of 4 points), see pack_head_kernel -------------------------------
         {
             const f32x4 acc = head_forward<NT>(wp, bias, x.v, lane);
@@ -357,6 +398,12 @@ __global__ __launch_bounds__(256) void field_tile_kernel(FieldArgs a) {
                 *reinterpret_cast<f32x4*>(a.rgb_sigma + ((size_t)b * a.n_per_image + nn) * 4) = o;
             }
         }
+        b = nb;
+        nn = nnn;
+        valid = nvalid;
+        px = nx;
+        py = ny;
+        pz = nz;
         STAMP(4);   // head
     }
 #ifdef CNERF_STAMPS
@@ -752,6 +799,16 @@ static int field_grid(const void* kernel, long long total_tiles) {
     return (blocks + 7) / 8 * 8;
 }
 
+static int field_grid_one_per_cu(long long total_tiles) {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+    const long long want = (total_tiles + 3) / 4;
+    int blocks = (int)(want < cus ? want : cus);
+    if (blocks < 8) blocks = 8;
+    return (blocks + 7) / 8 * 8;
+}
+
 template <int NT, bool HAS_RES>
 static hipError_t launch_field_backward_nt(const FieldArgs& a, hipStream_t stream) {
     const int blocks = field_grid((const void*)field_backward_kernel<NT, HAS_RES>, a.total_tiles);
@@ -775,16 +832,25 @@ hipError_t launch_field_backward(const FieldArgs& a, int H, hipStream_t stream) 
     }
 }
 
+template <int NT, bool HAS_RES, bool STORE>
+static hipError_t launch_field_tile(const FieldArgs& a, hipStream_t stream) {
+    if (a.n_in < 1 || a.in_level[0] < 0) return hipErrorInvalidValue;      // the lookup prefetch assumes a volume tile first
+    const void* fn = (const void*)field_tile_kernel<NT, HAS_RES, STORE>;
+    const int lds_bytes = (CNERF_F32_LOOKUP_DMA && NT >= 4) ? 4 * 32 * 1024 : 0;   // lookup staging of the four waves
+    static bool attr_set = false;
+    if (lds_bytes && !attr_set) {
+        if (hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)) return e;
+        attr_set = true;
+    }
+    const int blocks = lds_bytes ? field_grid_one_per_cu(a.total_tiles) : field_grid(fn, a.total_tiles);
+    hipLaunchKernelGGL((field_tile_kernel<NT, HAS_RES, STORE>), dim3(blocks), dim3(256), lds_bytes, stream, a);
+    return hipGetLastError();
+}
+
 template <int NT, bool HAS_RES>
 static hipError_t launch_field_nt(const FieldArgs& a, hipStream_t stream) {
-    if (a.act_h) {   // activation-storing forward of the backward pass
-        const int blocks = field_grid((const void*)field_tile_kernel<NT, HAS_RES, true>, a.total_tiles);
-        hipLaunchKernelGGL((field_tile_kernel<NT, HAS_RES, true>), dim3(blocks), dim3(256), 0, stream, a);
-    } else {
-        const int blocks = field_grid((const void*)field_tile_kernel<NT, HAS_RES, false>, a.total_tiles);
-        hipLaunchKernelGGL((field_tile_kernel<NT, HAS_RES, false>), dim3(blocks), dim3(256), 0, stream, a);
-    }
-    return hipGetLastError();
+    // a.act_h set: activation-storing forward of the backward pass
+    return a.act_h ? launch_field_tile<NT, HAS_RES, true>(a, stream) : launch_field_tile<NT, HAS_RES, false>(a, stream);
 }
 
 template <int NT>
