@@ -20,7 +20,7 @@
 // lockstep on four point tiles of the same image: each wave copies a quarter of the NEXT unit into the idle half of a
 // double buffer with LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave instruction, no VGPRs), all four read the CURRENT
 // one with ds_read_b128 (conflict-free: lane-linear 16 B), and one s_barrier per unit both publishes the DMA'd half and
-// retires the reads of the other.  Why (scripts/ubench/bf6_loop_model.hip, one wave per SIMD on all CUs, 20 VALU per
+// retires the reads of the other.  Why (scripts/ubench/split_loop_model.hip, one wave per SIMD on all CUs, 20 VALU per
 // k-chunk): with every wave streaming its own copy of the weights from L2 (4x the L2 -> CU traffic, ~20 TB/s aggregate)
 // a chunk of three MFMAs takes 123 ns, staged through LDS 97 ns, 65 ns for the MFMAs alone.  Biases, the per-layer
 // 2^-S factors and the image's freq / phase vectors live in LDS as well: vmcnt retires in order, so a wait for any

@@ -1,7 +1,7 @@
 // Microbenchmark: the inner loop of field_bf6_kernel in isolation, one wave per SIMD on every CU.
 // Per k-chunk: 3 x 16-B weight fragment loads (ring AHEAD chunks ahead) from a buffer of `bytes` (L2 resident at 1.2 MB,
 // L1 resident at 3 KiB), 6 dependent v_mfma_f32_32x32x16_bf16, K VALU ops (scalar v_fma_f32 or packed v_pk_fma_f32).
-// Prints cycles per chunk (ideal: 6 x 32 = 192).   Build: hipcc --offload-arch=gfx950 -O3 bf6_loop_model.hip
+// Prints cycles per chunk (ideal: 6 x 32 = 192).   Build: hipcc --offload-arch=gfx950 -O3 split_loop_model.hip
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
