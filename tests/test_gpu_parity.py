@@ -376,7 +376,8 @@ def test_render_matches_oracle_random_inputs(dev):
     assert scaled_err(pixels.cpu().numpy(), ref.pixels.numpy()) < TOL
 
 
-def _oracle_case(dev, variant, B, R, S, V, H, clamp="relu", noise=0.0, white=True, last=False, seed=0, check_grads=False):
+def _oracle_case(dev, variant, B, R, S, V, H, clamp="relu", noise=0.0, white=True, last=False, seed=0, check_grads=False,
+                 precision="fp32"):
     """Random inputs of an arbitrary shape: HIP vs the CPU oracle on the same rays / draws, fine depths forced."""
     import cnerf_amd
     from cnerf_amd.generators import ImplicitGenerator3d
@@ -399,6 +400,7 @@ def _oracle_case(dev, variant, B, R, S, V, H, clamp="relu", noise=0.0, white=Tru
                    rng["u_strat"], rng["eps_coarse"], rng["u_fine"], rng["eps_final"])
     gen.to(dev)
     gen.set_device(dev)
+    gen.siren.precision = precision
     r = {k: v.to(dev) for k, v in rng.items()}
     r["fine_z"] = ref.aux["fine_z"].to(dev)
     aux = {}
@@ -426,8 +428,17 @@ def _oracle_case(dev, variant, B, R, S, V, H, clamp="relu", noise=0.0, white=Tru
     dict(B=2, R=6, S=33, V=5),         # samples straddle the 32-point tiles and the 64-lane chunks
     dict(B=1, R=7, S=64, V=33),        # bench-like S, odd volume
 ])
-def test_ragged_and_extreme_shapes(dev, shape):
-    _oracle_case(dev, "SHORTSIREN_FG", H=64, **shape)
+@pytest.mark.parametrize("precision", ["fp32", "fp16x3"])
+def test_ragged_and_extreme_shapes(dev, shape, precision):
+    _oracle_case(dev, "SHORTSIREN_FG", H=64, precision=precision, **shape)
+
+
+@pytest.mark.parametrize("H", [128, 256])
+def test_split_precision_wide_ragged(dev, H):
+    """fp16x3 at the widths whose kernels stage weight units differently (4 / 8 output tiles), three images of a ragged
+    size (idle waves in the last tile group of every image, FiLM vectors restaged per image), softplus + noise."""
+    _oracle_case(dev, "SHORTSIREN_FG", B=3, R=9, S=11, V=12, H=H, clamp="softplus", noise=0.3, precision="fp16x3", seed=H)
+    _oracle_case(dev, "TALLSIREN_FG", B=2, R=6, S=13, V=10, H=H, precision="fp16x3", seed=H + 1)
 
 
 def test_extreme_shapes_other_families(dev):
