@@ -267,7 +267,34 @@ def build_unet3d():
     np.savez_compressed(os.path.join(HERE, "aux_unet3d_small.npz"), **out)
 
 
+def build_coordconv():
+    """aux_coordconv.npz: CoordConv and AdapterBlock as discriminators/sgdiscriminators.py defines them (the same source text
+    as in discriminators/discriminators.py, which cannot be imported here: it pulls in tkinter).  Pins the coordinate
+    channels (order, orientation, range) and the parameter names of the discriminator restatement's building blocks; the
+    assembly of ProgressiveDiscriminator itself (block list, fade-in) stays restated from source only."""
+    sys.path.insert(0, REF)
+    from discriminators import sgdiscriminators as sgd
+    torch.manual_seed(0)
+    cc = sgd.CoordConv(5, 7, kernel_size=3, padding=1)
+    ad = sgd.AdapterBlock(6)
+    x = torch.randn(2, 5, 6, 9)                  # non-square on purpose: rows and columns must not be swapped
+    img = torch.randn(2, 3, 4, 4)
+    with torch.no_grad():
+        y, a = cc(x), ad(img)
+    out = {"x": x.numpy(), "y": y.numpy(), "img": img.numpy(), "adapter_out": a.numpy()}
+    for k, v in cc.state_dict().items():
+        out["coordconv/" + k] = v.numpy()
+    for k, v in ad.state_dict().items():
+        out["adapter/" + k] = v.numpy()
+    np.savez_compressed(os.path.join(HERE, "aux_coordconv.npz"), **out)
+
+
 if __name__ == "__main__":
     names = sys.argv[1:] or list(FIXTURES)
     for n in names:
-        build_unet3d() if n == "unet3d" else build(n)
+        if n == "unet3d":
+            build_unet3d()
+        elif n == "coordconv":
+            build_coordconv()
+        else:
+            build(n)

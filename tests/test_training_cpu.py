@@ -30,6 +30,22 @@ def test_encoder_matches_reference_unet3d():
     assert np.abs(glob.numpy() - d["global_feature"]).max() < 1e-5
 
 
+def test_discriminator_building_blocks_match_reference():
+    """CoordConv and the fromRGB adapter against the reference's own classes (golden written by importing
+    discriminators/sgdiscriminators.py, whose CoordConv / AddCoords / AdapterBlock text is the one discriminators.py uses):
+    same parameter names, same coordinate channels on a non-square input."""
+    from cnerf_amd.training.discriminator import CoordConv, _FromRGB
+    d = np.load(os.path.join(GOLDEN_DIR, "aux_coordconv.npz"))
+    cc = CoordConv(5, 7, kernel_size=3, padding=1)
+    cc.load_state_dict({k[len("coordconv/"):]: torch.from_numpy(d[k]) for k in d.files if k.startswith("coordconv/")}, strict=True)
+    ad = _FromRGB(6)
+    ad.load_state_dict({k[len("adapter/"):]: torch.from_numpy(d[k]) for k in d.files if k.startswith("adapter/")}, strict=True)
+    with torch.no_grad():
+        y, a = cc(torch.from_numpy(d["x"])), ad(torch.from_numpy(d["img"]))
+    assert np.abs(y.numpy() - d["y"]).max() < 1e-6
+    assert np.abs(a.numpy() - d["adapter_out"]).max() < 1e-6
+
+
 @pytest.mark.parametrize("res", [32, 64, 128])
 def test_discriminator_resolutions_and_fade(res):
     from cnerf_amd.training import ProgressiveDiscriminator
