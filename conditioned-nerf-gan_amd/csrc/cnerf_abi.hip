@@ -333,6 +333,17 @@ int cnerf_gather_features(const cnerf_cfg* cfg, const float* fvol_cl, const floa
     return CNERF_OK;
 }
 
+int cnerf_scatter_features(const cnerf_cfg* cfg, const float* points, int64_t n_per_image, const float* grad_feat,
+                           float* grad_fvol_cl, void* stream) {
+    g_err[0] = 0;
+    if (int rc = check_cfg(cfg, false)) return rc;
+    if (!grad_fvol_cl || !points || !grad_feat || n_per_image < 1) return fail(CNERF_EINVAL, "scatter_features: bad argument");
+    if (cfg->C != 32 || cfg->n_levels > 1) return fail(CNERF_EINVAL, "scatter_features: single 32-channel volume only");
+    GatherArgs a{nullptr, points, nullptr, (long long)n_per_image, cfg->B, cfg->V, cfg->C, cfg->voxel_length / 2.0f};
+    if (hipError_t e = launch_scatter(a, grad_feat, grad_fvol_cl, (hipStream_t)stream)) return hip_fail(e, "scatter");
+    return CNERF_OK;
+}
+
 int cnerf_field_forward(const cnerf_cfg* cfg, const cnerf_volumes* vols, const float* packed, const float* freq,
                         const float* phase, const float* points, int64_t n_per_image, float* rgb_sigma, void* stream) {
     g_err[0] = 0;

@@ -147,5 +147,6 @@ struct GatherArgs {
     float half_voxel;
 };
 hipError_t launch_gather(const GatherArgs& a, hipStream_t stream);
+hipError_t launch_scatter(const GatherArgs& a, const float* grad_feat, float* grad_fvol, hipStream_t stream);
 
 }  // namespace cnerf

@@ -524,6 +524,29 @@ __global__ __launch_bounds__(256) void gather_kernel(GatherArgs a) {
     }
 }
 
+// Adjoint of gather_kernel: grad_fvol[corner k of point] += w_k * grad_feat[point] (8 lanes per point, 4 channels each, so
+// the 8 lanes of a point add one whole 128-B corner line per atomic instruction).  Used by the backward of the per-point
+// FiLM family, whose MLP gradients are evaluated by library GEMMs on the host side (ops._pfilm_backward).
+__global__ __launch_bounds__(256) void scatter_kernel(GatherArgs a, const float* __restrict__ grad_feat, float* __restrict__ grad_fvol) {
+    const int sub = threadIdx.x & 7;
+    const long long total = (long long)a.B * a.n_per_image;
+    const long long stride = (long long)gridDim.x * (blockDim.x >> 3);
+    for (long long pt = (long long)blockIdx.x * (blockDim.x >> 3) + (threadIdx.x >> 3); pt < total; pt += stride) {
+        const long long b = pt / a.n_per_image;
+        const float* p = a.points + pt * 3;
+        Corner8 cr;
+        trilinear_corners(p[0], p[1], p[2], a.half_voxel, a.V, cr);
+        const f32x4 g = *reinterpret_cast<const f32x4*>(grad_feat + pt * 32 + 4 * sub);
+        float* vol = grad_fvol + (size_t)b * a.V * a.V * a.V * 32 + 4 * sub;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float* dst = vol + (size_t)cr.base[k] * 32;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) atomicAdd(dst + e, g[e] * cr.w[k]);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 hipError_t launch_composite(const CompositeArgs& a, hipStream_t stream) {
     const unsigned blocks = (unsigned)((a.rays + RAYS_PER_BLOCK - 1) / RAYS_PER_BLOCK);
@@ -559,6 +582,15 @@ hipError_t launch_gather(const GatherArgs& a, hipStream_t stream) {
     if (blocks > 256 * 16) blocks = 256 * 16;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(gather_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_scatter(const GatherArgs& a, const float* grad_feat, float* grad_fvol, hipStream_t stream) {
+    const long long total = (long long)a.B * a.n_per_image;
+    long long blocks = (total + 31) / 32;
+    if (blocks > 65536) blocks = 65536;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(scatter_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a, grad_feat, grad_fvol);
     return hipGetLastError();
 }
 

@@ -4,6 +4,7 @@ import ctypes as C
 from typing import Dict, Optional
 
 import torch
+import torch.nn.functional as F
 
 from . import _lib as L
 
@@ -291,12 +292,74 @@ def pack_field_transposed(net, cfg):
 ACT_BUDGET_BYTES = 48 << 30     # activation / gradient chunk buffers of the backward (288 GB HBM per GPU)
 
 
+PFILM_CHUNK_POINTS = 1 << 17    # points per chunk of the per-point-FiLM backward (~60 KB of activations per point)
+
+
+def _pfilm_mlp(spec, ps, feat, pts, H):
+    """TALLSIREN on looked-up features (siren.py:232-331): m = LeakyReLU_0.2(Wm1 feat + bm1); (freq | phase) = Wm2 m + bm2,
+    freq * 15 + 30; x = xyz; x = sin(freq_l * (W_l x + b_l) + phase_l) per layer; head.  Plain torch ops: the backward
+    of this family runs its dense algebra as library GEMMs."""
+    nl = len(spec.layers)
+    m = F.leaky_relu(F.linear(feat, ps[0], ps[1]), 0.2)
+    fo = F.linear(m, ps[2], ps[3])
+    half = fo.shape[-1] // 2
+    freq, phase = fo[..., :half] * 15 + 30, fo[..., half:]
+    x = pts
+    for l in range(nl):
+        x = torch.sin(freq[..., l * H:(l + 1) * H] * F.linear(x, ps[4 + 2 * l], ps[5 + 2 * l]) + phase[..., l * H:(l + 1) * H])
+    out = F.linear(x, ps[4 + 2 * nl], ps[5 + 2 * nl])
+    if spec.sigmoid_rgb:
+        out = torch.cat([torch.sigmoid(out[..., :3]), out[..., 3:]], -1)
+    return out
+
+
+def _pfilm_backward(net, cfg, levels, saved, gc, gf, hier):
+    """Field gradients of the per-point FiLM family: per chunk of points, features from cnerf_gather_features, the MLP
+    re-evaluated and differentiated by torch (rocBLAS GEMMs), feature gradients scattered by cnerf_scatter_features."""
+    fvol = levels[0]
+    B = fvol.shape[0]
+    H = int(net.hidden_dim)
+    ps = [p.detach().requires_grad_(True) for p in net.field_params()]
+    grads = [torch.zeros_like(p) for p in ps]
+    g_level = torch.zeros_like(fvol)
+    c_pts, f_pts = saved[4], saved[5]
+    cfg1 = make_cfg(net, 1, int(fvol.shape[1]))
+    for pts_all, g_all in [(c_pts, gc)] + ([(f_pts, gf)] if hier else []):
+        pts_all = pts_all.reshape(B, -1, 3)
+        g_all = g_all.reshape(B, -1, 4)
+        n = pts_all.shape[1]
+        for b in range(B):
+            for s0 in range(0, n, PFILM_CHUNK_POINTS):
+                pts = pts_all[b, s0:s0 + PFILM_CHUNK_POINTS].contiguous()
+                feat = gather_features(net, fvol[b:b + 1], pts.unsqueeze(0))[0].requires_grad_(True)
+                with torch.enable_grad():
+                    out = _pfilm_mlp(net.spec, ps, feat, pts, H)
+                gs = torch.autograd.grad(out, ps + [feat], g_all[b, s0:s0 + PFILM_CHUNK_POINTS])
+                for acc, g in zip(grads, gs[:-1]):
+                    acc += g
+                d_feat = gs[-1].contiguous()
+                L.check(L.lib().cnerf_scatter_features(C.byref(cfg1), L.ptr(pts), pts.shape[0], L.ptr(d_feat),
+                                                       L.ptr(g_level[b:b + 1]), _stream()), "cnerf_scatter_features")
+    return [g_level], None, None, grads
+
+
 def render_backward(net, o, levels, freq, phase, cam2world, rng, saved, grad_pixels, grad_depth):
     """Gradients of one render w.r.t. (channel-last feature volumes, freq, phase, [field parameters])."""
     B, R, S, hier = o["B"], o["R"], o["S"], o["hier"]
     dev = cam2world.device
     cfg = make_cfg(net, B, levels, R, S, o["fov"], o["ray_start"], o["ray_end"], o["noise_std"], hier,
                    o["white_back"], o["last_back"], o["clamp_mode"], precision="fp32")   # the backward is fp32
+    if net.spec.layers[0] == "pfilm":
+        c_rs, c_z, f_rs, f_z = saved[:4]
+        gc = torch.empty_like(c_rs)
+        gf = torch.empty_like(f_rs) if hier else None
+        eps_final = _f32(rng.get("eps_final")) if o["noise_std"] != 0 else None
+        gd = _f32(grad_depth) if grad_depth is not None else None
+        L.check(L.lib().cnerf_merge_composite_backward(C.byref(cfg), L.ptr(c_rs), L.ptr(c_z), L.ptr(f_rs) if hier else None,
+                                                       L.ptr(f_z) if hier else None, L.ptr(eps_final), L.ptr(_f32(grad_pixels)),
+                                                       L.ptr(gd), L.ptr(gc), L.ptr(gf) if hier else None, _stream()),
+                "cnerf_merge_composite_backward")
+        return _pfilm_backward(net, cfg, levels, saved, gc, gf, hier)
     vs = volumes_struct(levels)
     packed = pack_field(net, cfg)
     packed_t = pack_field_transposed(net, cfg)
@@ -305,7 +368,7 @@ def render_backward(net, o, levels, freq, phase, cam2world, rng, saved, grad_pix
     kinds = net.spec.layers
     nl = len(kinds)
     npi = R * R * S
-    c_rs, c_z, f_rs, f_z = saved
+    c_rs, c_z, f_rs, f_z = saved[:4]
     gc = torch.empty_like(c_rs)
     gf = torch.empty_like(f_rs) if hier else None
     grad_pixels = _f32(grad_pixels)
@@ -397,14 +460,15 @@ class RenderFunction(torch.autograd.Function):
         fr = freq.detach() if freq is not None else None
         ph = phase.detach() if phase is not None else None
         need_grad = any(ctx.needs_input_grad)   # (grad mode is always off inside Function.forward)
+        keys = SAVED_KEYS + (("coarse_points", "fine_points") if net.spec.layers[0] == "pfilm" else ())   # see _pfilm_backward
         pixels, depth, aux = render_forward(net, levels, fr, ph, cam2world, o["R"], o["fov"], o["ray_start"], o["ray_end"],
                                             o["S"], o["hier"], o["clamp_mode"], o["noise_std"], o["white_back"],
                                             o["last_back"], rng, want_aux=o["want_aux"], fvol_is_channel_last=True,
                                             field_events=o.get("field_events"),
-                                            aux_keys=SAVED_KEYS if need_grad and not o["want_aux"] else None)
+                                            aux_keys=keys if need_grad and not o["want_aux"] else None)
         ctx.net, ctx.o, ctx.rng, ctx.n_vols = net, o, rng, n_vols
         if need_grad:
-            saved = [aux.get(k) for k in SAVED_KEYS]
+            saved = [aux.get(k) for k in keys]
             if o["hier"] and rng.get("fine_z") is not None:
                 saved[3] = _f32(rng["fine_z"]).reshape(saved[1].shape)   # teacher-forced depths are what the fine pass used
             ctx.saved = (levels, fr, ph, _f32(cam2world), tuple(saved))

@@ -166,6 +166,12 @@ int cnerf_pack_field(const cnerf_cfg* cfg, const cnerf_field_params* params, flo
 int cnerf_gather_features(const cnerf_cfg* cfg, const float* fvol_cl, const float* points, int64_t n_per_image,
                           float* feat, void* stream);
 
+/* Adjoint of cnerf_gather_features: grad_fvol_cl (B,V,V,V,32) += scatter of grad_feat (B,n,32) with the trilinear weights of
+ * points (B,n,3).  Autograd twin of F.grid_sample (siren.py:555-571) for hosts that evaluate the MLP gradients themselves
+ * (the per-point FiLM family, siren.py:232-331). */
+int cnerf_scatter_features(const cnerf_cfg* cfg, const float* points, int64_t n_per_image, const float* grad_feat,
+                           float* grad_fvol_cl, void* stream);
+
 /* Field network at explicit points: points (B,n,3) -> rgb_sigma (B,n,4).
  * Replaces <SIREN>.forward(points, z, img_size, num_steps) (siren.py:637-668 and siblings; extract_shapes.py:63-69).
  * freq/phase: (B, n_film*H) with freq already *15+30 (siren.py:650), NULL when the network has no FiLM layer. */

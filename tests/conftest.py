@@ -14,7 +14,7 @@ GOLDEN_NAMES = sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz
 SMALL_GOLDEN = [n for n in GOLDEN_NAMES if n.endswith("_small") or n in ("short_fg_nohier", "short_fg_s40")]
 # fixtures the HIP path does not implement yet (the oracle and the host mirror do): per-point FiLM
 NOT_ON_GPU_YET = set()
-NO_BACKWARD_YET = {"tallsiren_small"}
+NO_BACKWARD_YET = set()
 
 
 def pytest_configure(config):

@@ -446,6 +446,27 @@ def test_extreme_shapes_other_families(dev):
     _oracle_case(dev, "DOUBLESIREN_FG", B=1, R=4, S=17, V=4, H=128, white=False)
 
 
+def test_scatter_is_the_adjoint_of_gather(dev):
+    """cnerf_scatter_features against cnerf_gather_features: <gather(v), g> == <v, scatter(g)> for random v, g, points (incl.
+    points outside the volume, which clamp to the border like the lookup does)."""
+    import ctypes as C
+    import cnerf_amd
+    from cnerf_amd import ops, _lib as L
+    from cnerf_amd.generators import ImplicitGenerator3d
+    torch.manual_seed(3)
+    net = ImplicitGenerator3d("SHORTSIREN_FG", 16, 32, 4, 64).to(dev).siren
+    B, V, n = 2, 6, 1000
+    vol = torch.randn(B, V, V, V, 32, device=dev)
+    pts = (torch.rand(B, n, 3, device=dev) - 0.5) * 1.6            # |coordinate| up to 0.8 > 0.6: border clamp exercised
+    g = torch.randn(B, n, 32, device=dev)
+    feat = ops.gather_features(net, vol, pts)
+    out = torch.zeros_like(vol)
+    cfg = ops.make_cfg(net, B, V)
+    L.check(L.lib().cnerf_scatter_features(C.byref(cfg), L.ptr(pts), n, L.ptr(g), L.ptr(out), ops._stream()), "scatter")
+    lhs, rhs = (feat.double() * g.double()).sum().item(), (vol.double() * out.double()).sum().item()
+    assert abs(lhs - rhs) < 1e-4 * max(1.0, abs(lhs))
+
+
 def test_bad_arguments_are_refused(dev):
     """Shapes outside the supported range come back as CnerfError with a message, never as a wrong image."""
     import cnerf_amd
