@@ -76,6 +76,9 @@ struct Act {
 #endif
 constexpr int RING = CNERF_RING;
 
+// Forward epilogue sine.  v_sin_f32 behind an exact reduction by 2 pi (max abs error 3.8e-7, scripts/ubench/vsin_accuracy.hip)
+// instead of the 12-op polynomial (1.2e-7) is +1.7 % throughput, but on this exact path it pushes one random-input parity
+// case (test_render_matches_oracle_random_inputs, sigma head x30) from 0.9e-4 to 1.03e-4 of the 1e-4 gate: off.
 #ifndef CNERF_F32_HW_SIN
 #define CNERF_F32_HW_SIN 0
 #endif
