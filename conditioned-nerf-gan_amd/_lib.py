@@ -57,6 +57,8 @@ PROTOTYPES = {
     "cnerf_fvol_channel_first": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cnerf_pack_field": (C.c_int, [C.POINTER(Cfg), C.POINTER(FieldParams), C.c_void_p, C.c_void_p]),
     "cnerf_gather_features": (C.c_int, [C.POINTER(Cfg), C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "cnerf_weight_grad": (C.c_int, [C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_void_p]),
     "cnerf_scatter_features": (C.c_int, [C.POINTER(Cfg), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cnerf_field_forward": (C.c_int, [C.POINTER(Cfg), C.POINTER(Volumes), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_int64, C.c_void_p, C.c_void_p]),

@@ -333,6 +333,18 @@ int cnerf_gather_features(const cnerf_cfg* cfg, const float* fvol_cl, const floa
     return CNERF_OK;
 }
 
+int cnerf_weight_grad(int32_t n_images, int64_t n_per_image, int32_t H, int32_t K, const float* g_arg, const float* x, float* dW,
+                      float* colsum, void* stream) {
+    g_err[0] = 0;
+    if (!g_arg || !x || !dW || !colsum) return fail(CNERF_EINVAL, "weight_grad: NULL argument");
+    if (n_images < 1 || n_per_image < 1) return fail(CNERF_EINVAL, "weight_grad: empty chunk");
+    if ((H != 64 && H != 128 && H != 256) || K < 32 || K > 256 || K % 32)
+        return fail(CNERF_EINVAL, "weight_grad: H=%d must be 64/128/256 and K=%d a multiple of 32 up to 256", H, K);
+    if (hipError_t e = launch_weight_grad(n_images, n_per_image, H, K, g_arg, x, dW, colsum, (hipStream_t)stream))
+        return hip_fail(e, "weight_grad");
+    return CNERF_OK;
+}
+
 int cnerf_scatter_features(const cnerf_cfg* cfg, const float* points, int64_t n_per_image, const float* grad_feat,
                            float* grad_fvol_cl, void* stream) {
     g_err[0] = 0;

@@ -149,4 +149,7 @@ struct GatherArgs {
 hipError_t launch_gather(const GatherArgs& a, hipStream_t stream);
 hipError_t launch_scatter(const GatherArgs& a, const float* grad_feat, float* grad_fvol, hipStream_t stream);
 
+hipError_t launch_weight_grad(int cnt, long long npi, int H, int K, const float* G, const float* X, float* dW, float* colsum,
+                              hipStream_t stream);
+
 }  // namespace cnerf

@@ -422,12 +422,14 @@ def render_backward(net, o, levels, freq, phase, cam2world, rng, saved, grad_pix
             # parameter gradients: plain GEMMs and column sums over the chunk matrices (rocBLAS through torch)
             fidx = 0
             for l, kind in enumerate(slab_of):
-                X = (a_feat if l == 0 else a_h[l - 1]).view(cnt, npi, -1)
-                G = a_g[l].view(cnt, npi, H)
-                dWarg = torch.bmm(G.transpose(1, 2), X)          # (cnt, H, K) per image
+                X = a_feat if l == 0 else a_h[l - 1]
+                K = X.shape[-1]
+                dWarg = torch.zeros((cnt, H, K), dtype=torch.float32, device=dev)    # per image: G^T X
+                cs = torch.zeros((cnt, H), dtype=torch.float32, device=dev)          # per image: column sums of G
+                L.check(L.lib().cnerf_weight_grad(cnt, npi, H, K, L.ptr(a_g[l]), L.ptr(X), L.ptr(dWarg), L.ptr(cs), _stream()),
+                        "cnerf_weight_grad")
                 if l == 0:
                     dWarg = dWarg[..., :k0]                      # drop the zero padding of the last input tile
-                cs = G.sum(1)                                    # (cnt, H)
                 if kind == "film":
                     sl = slice(fidx * H, (fidx + 1) * H)
                     f = freq[b0:b0 + cnt, sl]

@@ -449,6 +449,23 @@ def test_extreme_shapes_other_families(dev):
     _oracle_case(dev, "DOUBLESIREN_FG", B=1, R=4, S=17, V=4, H=128, white=False)
 
 
+@pytest.mark.parametrize("shape", [(2, 1000, 256, 256), (1, 37, 64, 32), (3, 5003, 128, 64), (2, 4099, 256, 192), (1, 70000, 256, 96)])
+def test_weight_grad_kernel(dev, shape):
+    """cnerf_weight_grad (per-image G^T X and column sums over a chunk) against float64 matmuls: ragged point counts, every
+    supported width, both outputs accumulate."""
+    import cnerf_amd
+    from cnerf_amd import ops, _lib as L
+    cnt, npi, H, K = shape
+    torch.manual_seed(cnt * 7 + K)
+    G, X = torch.randn(cnt, npi, H, device=dev), torch.randn(cnt, npi, K, device=dev)
+    dW, cs = torch.ones(cnt, H, K, device=dev), torch.ones(cnt, H, device=dev)          # accumulated into
+    L.check(L.lib().cnerf_weight_grad(cnt, npi, H, K, L.ptr(G), L.ptr(X), L.ptr(dW), L.ptr(cs), ops._stream()), "weight_grad")
+    ref = torch.bmm(G.transpose(1, 2).double(), X.double()) + 1
+    rcs = G.double().sum(1) + 1
+    assert ((dW.double() - ref).abs().max() / ref.abs().max()).item() < 5e-6
+    assert ((cs.double() - rcs).abs().max() / rcs.abs().max()).item() < 5e-6
+
+
 def test_scatter_is_the_adjoint_of_gather(dev):
     """cnerf_scatter_features against cnerf_gather_features: <gather(v), g> == <v, scatter(g)> for random v, g, points (incl.
     points outside the volume, which clamp to the border like the lookup does)."""
