@@ -36,9 +36,20 @@ def default_metadata(img_size=128, num_steps=64, batch_size=8, batch_split=4, si
 class GanTrainer:
     def __init__(self, metadata, device, ddp=False):
         self.metadata, self.device, self.ddp = metadata, device, ddp
+        # MIOpen find mode for the 3-D convolutions of the encoder (and the discriminator): without it the immediate-mode
+        # heuristic picks a naive weight-gradient solver for several Conv3d shapes -- encoder forward + backward of 2 voxel
+        # grids 371 ms against 22 ms with the search (scripts/encoder_profile.py), i.e. 75 % of the whole GAN step.
+        # Opt-in (train.py turns it on): the search itself takes minutes on a fresh machine, once per convolution shape.
+        if metadata.get("miopen_find", False):
+            torch.backends.cudnn.benchmark = True
         self.generator = ImplicitGenerator3d(**metadata["generator"]).to(device)
         self.generator.set_device(device)
+        # arithmetic of the forward render (both the no-grad D-step images and the G-step forward; the backward kernels are
+        # fp32 either way): "fp32" or the fp32-accurate split "fp16x3" (same parity gate, 2.7x faster)
+        self.generator.siren.precision = metadata.get("render_precision", "fp32")
         self.encoder = UNet3D(**metadata["unet"]).to(device)
+        if metadata.get("encoder_channels_last", False):     # NDHWC convolutions (MIOpen); off by default: measured below
+            self.encoder = self.encoder.to(memory_format=torch.channels_last_3d)
         self.discriminator = ProgressiveDiscriminator().to(device)
         wrap = (lambda m, unused: DDP(m, device_ids=[device.index], find_unused_parameters=unused)) if ddp else (lambda m, unused: m)
         self.generator_ddp = wrap(self.generator, True)

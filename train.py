@@ -30,6 +30,9 @@ def main():
     ap.add_argument("--voxel-res", type=int, default=64)
     ap.add_argument("--siren-type", default="SHORTSIREN_FG")
     ap.add_argument("--hidden", type=int, default=256)
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "fp16x3"], help="arithmetic of the forward render")
+    ap.add_argument("--no-miopen-find", action="store_true",
+                    help="keep MIOpen's immediate-mode kernel choice for the Conv3d/Conv2d layers (fast start, 3x slower steps)")
     ap.add_argument("-p", "--print-freq", type=int, default=1)
     args = ap.parse_args()
 
@@ -52,8 +55,21 @@ def main():
     torch.manual_seed(rank)
     np.random.seed(rank)
     md = default_metadata(args.img_size, args.num_steps, args.batch, args.batch_split, args.siren_type, args.hidden)
+    md["render_precision"] = args.precision
+    md["miopen_find"] = not args.no_miopen_find
+    md["encoder_channels_last"] = bool(int(os.environ.get("CNERF_ENCODER_CHANNELS_LAST", "0")))
     trainer = GanTrainer(md, dev, ddp=world > 1)
     gen = torch.Generator().manual_seed(1000 + rank)
+    import threading
+    first_done = threading.Event()
+
+    def heartbeat():                       # the first step selects (and compiles) MIOpen kernels: minutes with the search on
+        t0 = time.perf_counter()
+        while not first_done.wait(60.0):
+            print(f"... first step still running ({time.perf_counter() - t0:.0f} s: MIOpen kernel selection)", flush=True)
+
+    if rank == 0:
+        threading.Thread(target=heartbeat, daemon=True).start()
     for step in range(args.steps):
         sample = synthetic_sample(args.batch, args.img_size, args.voxel_res, dev, gen)
         torch.cuda.synchronize()
@@ -61,6 +77,7 @@ def main():
         trainer.step(sample)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        first_done.set()
         if rank == 0 and step % args.print_freq == 0:
             print(f"step {step}: D {trainer.losses['d'][-1]:.4f}  G {trainer.losses['g'][-1]:.4f}  photo {trainer.losses['photo'][-1]:.4f}  "
                   f"alpha {trainer.alpha:.3f}  nerf_noise {md['nerf_noise']:.3f}  sec/step {dt:.3f}  "
