@@ -506,15 +506,19 @@ def test_bad_arguments_are_refused(dev):
         gen((fv, gl), cam, 4, 30.0, 0.1, 1.0, 8, True, nerf_noise=0.0)
 
 
-def test_full_size_properties(dev):
-    """BASELINE size 128x128x64 (B=1): properties that need no oracle -- weights form a sub-probability, white
-    background fills the missing mass, depth within [ray_start, ray_end]*dir_z, determinism across two runs."""
+@pytest.mark.parametrize("size", [(128, 64, "fp32"), (128, 64, "fp16x3"), (256, 96, "fp32"), (256, 96, "fp16x3")])
+def test_full_size_properties(dev, size):
+    """BASELINE sizes 128x128x64 (configs 3/4) and 256x256x96 (config 5), B=1: properties that need no oracle -- weights
+    form a sub-probability, white background fills the missing mass, depth within [ray_start, ray_end]*dir_z, determinism
+    across two runs; both precisions."""
     import cnerf_amd
     from cnerf_amd.generators import ImplicitGenerator3d
     torch.manual_seed(0)
-    R, S, V = 128, 64, 64
+    R, S, prec = size
+    V = 64
     gen = ImplicitGenerator3d("SHORTSIREN_FG", 256, 32, 4, 256).to(dev)
     gen.set_device(dev)
+    gen.siren.precision = prec
     with torch.no_grad():
         gen.siren.final_layer.weight[3] *= 40
     fvol, glob = torch.randn(1, 32, V, V, V, device=dev), torch.randn(1, 256, device=dev)
