@@ -185,7 +185,7 @@ int fill_field_args(FieldArgs& a, const cnerf_cfg* c, const cnerf_volumes* vols,
 }
 
 hipError_t launch_forward(const FieldArgs& a, const cnerf_cfg* c, hipStream_t stream) {
-    return (c->precision == CNERF_PREC_FP16X3 && !a.act_h) ? launch_field_h3(a, c->H, stream) : launch_field(a, c->H, stream);
+    return c->precision == CNERF_PREC_FP16X3 ? launch_field_h3(a, c->H, stream) : launch_field(a, c->H, stream);
 }
 
 void set_points(FieldArgs& a, int B, long long n_per_image) {
@@ -529,7 +529,6 @@ int cnerf_field_backward(const cnerf_cfg* cfg, int32_t pass, int32_t image0, int
     g_err[0] = 0;
     if (int rc = check_cfg(cfg, true)) return rc;
     if (cfg->layer_kind[0] == CNERF_LAYER_PFILM) return fail(CNERF_ENOSYS, "backward of the per-point FiLM family is not implemented");
-    if (cfg->precision != CNERF_PREC_FP32) return fail(CNERF_EINVAL, "field_backward runs in fp32: pass a cfg with precision = CNERF_PREC_FP32 and fp32-packed weights");
     if (image0 < 0 || n_images < 1 || image0 + n_images > cfg->B) return fail(CNERF_EINVAL, "field_backward: image range out of [0,B)");
     if (pass < 0 || pass > 2) return fail(CNERF_EINVAL, "field_backward: pass must be 0 (coarse), 1 (fine) or 2 (explicit points)");
     if (!vols || !packed || !packed_t || !cam2world || !grad_rgb_sigma || !saved_rgb_sigma || !act_feat || !act_h || !act_c ||
@@ -564,7 +563,9 @@ int cnerf_field_backward(const cnerf_cfg* cfg, int32_t pass, int32_t image0, int
     fa.act_feat = act_feat;
     fa.act_h = act_h;
     fa.act_c = act_c;
-    if (hipError_t e = launch_field(fa, cfg->H, stream)) return hip_fail(e, "field kernel (activation store)");
+    // the activation-storing forward runs in cfg->precision (`packed` is in that precision's layout); the gradient chain
+    // below is fp32 on the transposed fp32 weights either way
+    if (hipError_t e = launch_forward(fa, cfg, stream)) return hip_fail(e, "field kernel (activation store)");
     fa.packed_t = packed_t;
     fa.grad_out = grad_rgb_sigma + (size_t)image0 * npi * 4;
     fa.saved_out = saved_rgb_sigma + (size_t)image0 * npi * 4;

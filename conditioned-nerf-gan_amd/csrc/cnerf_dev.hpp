@@ -77,6 +77,17 @@ __device__ __forceinline__ float sin_2pi_reduced_hw(float x) {
     return __builtin_amdgcn_sinf(r * 0.15915494309189535f);
 }
 
+// sine and cosine of the same argument on the transcendental unit (shared reduction): the activation-storing forward
+__device__ __forceinline__ void sincos_2pi_reduced_hw(float x, float& sn, float& cs) {
+    const float t = __builtin_fmaf(x, 0.15915494309189535f, SIN_MAGIC);
+    const float n = t - SIN_MAGIC;
+    float r = __builtin_fmaf(-n, 6.2831854820251465f, x);
+    r = __builtin_fmaf(-n, -1.7484555314695172e-07f, r);
+    const float u = r * 0.15915494309189535f;
+    sn = __builtin_amdgcn_sinf(u);
+    cs = __builtin_amdgcn_cosf(u);
+}
+
 __device__ __forceinline__ f32x2 sin_2pi_reduced_hw2(f32x2 x) {     // two arguments, reduction on the packed fp32 ops
     const f32x2 t = __builtin_elementwise_fma(x, splat2(0.15915494309189535f), splat2(SIN_MAGIC));
     const f32x2 n = t - splat2(SIN_MAGIC);

@@ -29,13 +29,6 @@
 #include "cnerf_kernels.hpp"
 #include "field_common.hpp"
 
-#ifndef CNERF_H3_PACKED_MATH
-#define CNERF_H3_PACKED_MATH 0
-#endif
-#ifndef CNERF_H3_HW_SIN
-#define CNERF_H3_HW_SIN 1
-#endif
-
 namespace cnerf {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -149,34 +142,43 @@ __device__ __forceinline__ FilmPair film_pair_load(const float* lbias, const flo
     return f;
 }
 
+// Activation rows of the lane's point for the layer being produced (activation-storing forward of the backward pass):
+// sin(arg) goes to act_h, cos(arg) to act_c, four consecutive channels (two pairs) per 16-byte store.
+struct ActStore {
+    float* row_h;
+    float* row_c;
+    float ks[2], kc[2];      // the first pair of a quad, held until the second one arrives
+};
+
 // acc holds S * (W x) of accumulator elements r, r+1 (r even): pre = acc / S + bias in one rounding (S is a power of
 // two), FiLM with product and sum rounded separately like the reference (a plain sine layer runs with freq = 1,
 // phase = 0, which is exact -- one branch-free code path), sine, split into the fragments of the chunk pair `out2`
-// (element r of the tile is element r & 7 of chunk r >> 3).
-__device__ __forceinline__ void film_split_pair(const f32x16& acc, float inv_s, const FilmPair& f, int r, Split2* out2) {
-#if CNERF_H3_HW_SIN && CNERF_H3_PACKED_MATH
-    f32x2 pre = __builtin_elementwise_fma(f32x2{acc[r], acc[r + 1]}, splat2(inv_s), f.bs);
-    pre = f.fr * pre + f.ph;
-    const f32x2 v = sin_2pi_reduced_hw2(pre);
-    const float v0 = v[0], v1 = v[1];
-#elif CNERF_H3_HW_SIN
+// (element r of the tile is element r & 7 of chunk r >> 3).  Pairs of a tile must arrive in order r = 0, 2, 4, ...
+template <bool STORE>
+__device__ __forceinline__ void film_split_pair(const f32x16& acc, float inv_s, const FilmPair& f, int t, int h, int r, Split2* out2,
+                                                ActStore& st) {
     float a0 = __builtin_fmaf(acc[r], inv_s, f.bs[0]), a1 = __builtin_fmaf(acc[r + 1], inv_s, f.bs[1]);
     a0 = f.fr[0] * a0 + f.ph[0];
     a1 = f.fr[1] * a1 + f.ph[1];
-    const float v0 = sin_2pi_reduced_hw(a0);
-    const float v1 = sin_2pi_reduced_hw(a1);
-#elif CNERF_H3_PACKED_MATH
-    f32x2 pre = __builtin_elementwise_fma(f32x2{acc[r], acc[r + 1]}, splat2(inv_s), f.bs);
-    pre = f.fr * pre + f.ph;
-    const f32x2 v = sin_pi_reduced2(pre);
-    const float v0 = v[0], v1 = v[1];
-#else
-    float a0 = __builtin_fmaf(acc[r], inv_s, f.bs[0]), a1 = __builtin_fmaf(acc[r + 1], inv_s, f.bs[1]);
-    a0 = f.fr[0] * a0 + f.ph[0];
-    a1 = f.fr[1] * a1 + f.ph[1];
-    const float v0 = sin_pi_reduced(a0);
-    const float v1 = sin_pi_reduced(a1);
-#endif
+    float v0, v1;
+    if (STORE) {
+        float c0, c1;
+        sincos_2pi_reduced_hw(a0, v0, c0);
+        sincos_2pi_reduced_hw(a1, v1, c1);
+        if ((r & 2) == 0) {
+            st.ks[0] = v0;
+            st.ks[1] = v1;
+            st.kc[0] = c0;
+            st.kc[1] = c1;
+        } else {
+            const int ch = 32 * t + 8 * (r >> 2) + 4 * h;
+            *reinterpret_cast<f32x4*>(st.row_h + ch) = f32x4{st.ks[0], st.ks[1], v0, v1};
+            *reinterpret_cast<f32x4*>(st.row_c + ch) = f32x4{st.kc[0], st.kc[1], c0, c1};
+        }
+    } else {
+        v0 = sin_2pi_reduced_hw(a0);
+        v1 = sin_2pi_reduced_hw(a1);
+    }
     Split2& d = out2[r >> 3];
     switch (r & 7) {
         case 0: split_pair<0>(v0, v1, d); break;
@@ -187,14 +189,15 @@ __device__ __forceinline__ void film_split_pair(const f32x16& acc, float inv_s, 
 }
 
 // whole tile at once (layer 0 and the last output tile of a layer), FiLM pairs fetched one step ahead
+template <bool STORE>
 __device__ __forceinline__ void film_split(const f32x16& acc, float inv_s, const float* lbias, const float* lfr, const float* lph, int t,
-                                           int h, Split2* out2) {
+                                           int h, Split2* out2, ActStore& st) {
     FilmPair f = film_pair_load(lbias, lfr, lph, t, h, 0);
 #pragma unroll
     for (int r = 0; r < 16; r += 2) {
         const FilmPair fcur = f;
         if (r + 2 < 16) f = film_pair_load(lbias, lfr, lph, t, h, r + 2);
-        film_split_pair(acc, inv_s, fcur, r, out2);
+        film_split_pair<STORE>(acc, inv_s, fcur, t, h, r, out2, st);
     }
 }
 
@@ -342,7 +345,7 @@ __device__ __forceinline__ TilePoint tile_of_group(const FieldArgs& a, long long
     return p;
 }
 
-template <int NT>
+template <int NT, bool STORE>
 __global__ __launch_bounds__(256) void field_h3_kernel(FieldArgs a) {
 #ifdef CNERF_STAMPS
     unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -415,6 +418,11 @@ __global__ __launch_bounds__(256) void field_h3_kernel(FieldArgs a) {
         const float* lph = lds_phase;
 
         Split2 x[KCH], y[KCH];
+        ActStore st;
+        const size_t gpt = (size_t)b * a.n_per_image + nn;            // row of the lane's point in the chunk's activation buffers
+        const size_t act_layer = (size_t)a.act_points * H;
+        st.row_h = STORE ? a.act_h + gpt * H : nullptr;
+        st.row_c = STORE ? a.act_c + gpt * H : nullptr;
         // ---- layer 0: one weight unit per input tile ------------------------------------------------------------------
         {
             f32x16 acc0[NT];
@@ -435,6 +443,11 @@ __global__ __launch_bounds__(256) void field_h3_kernel(FieldArgs a) {
                 float fv[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) fv[r] = feat[r];
+                if (STORE) {
+                    float* fo = a.act_feat + gpt * (32 * a.n_in) + 32 * tk + 4 * h;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4*>(fo + 8 * g) = f32x4{fv[4 * g], fv[4 * g + 1], fv[4 * g + 2], fv[4 * g + 3]};
+                }
                 Split2 f2[2];
                 f2[0] = split8_clamped(fv);
                 f2[1] = split8_clamped(fv + 8);
@@ -445,7 +458,11 @@ __global__ __launch_bounds__(256) void field_h3_kernel(FieldArgs a) {
             const bool film = a.layer_kind[0] == CNERF_LAYER_FILM;
             const float inv_s = lds_inv_s[0];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) film_split(acc0[t], inv_s, bias, film ? lfr : lds_ones, film ? lph : lds_zeros, t, h, &x[2 * t]);
+            for (int t = 0; t < NT; ++t) film_split<STORE>(acc0[t], inv_s, bias, film ? lfr : lds_ones, film ? lph : lds_zeros, t, h, &x[2 * t], st);
+            if (STORE) {
+                st.row_h += act_layer;
+                st.row_c += act_layer;
+            }
             bias += H;
             if (film) {
                 lfr += H;
@@ -472,19 +489,23 @@ __global__ __launch_bounds__(256) void field_h3_kernel(FieldArgs a) {
                 acc = h3_tile_from_lds<NT, 7>(lds + cur * UNIT_FR, x, acc, lane, [&](int c) {
                     if (t > 0 && c < 16) {                     // epilogue of tile t-1, one pair of elements per two chunks
                         if (!(c & 1)) fp = film_pair_load(bias, fr_l, ph_l, t - 1, h, c);
-                        else film_split_pair(acc_prev, inv_s, fp, c - 1, &y[2 * (t - 1)]);
+                        else film_split_pair<STORE>(acc_prev, inv_s, fp, t - 1, h, c - 1, &y[2 * (t - 1)], st);
                     }
                 });
                 if (t > 0 && KCH < 16) {                       // narrow networks: the rest of tile t-1's elements
 #pragma unroll
                     for (int r = KCH; r < 16; r += 2)
-                        film_split_pair(acc_prev, inv_s, film_pair_load(bias, fr_l, ph_l, t - 1, h, r), r, &y[2 * (t - 1)]);
+                        film_split_pair<STORE>(acc_prev, inv_s, film_pair_load(bias, fr_l, ph_l, t - 1, h, r), t - 1, h, r, &y[2 * (t - 1)], st);
                 }
                 acc_prev = acc;
                 cur ^= 1;
                 ++seq;
             }
-            film_split(acc_prev, inv_s, bias, fr_l, ph_l, NT - 1, h, &y[2 * (NT - 1)]);
+            film_split<STORE>(acc_prev, inv_s, bias, fr_l, ph_l, NT - 1, h, &y[2 * (NT - 1)], st);
+            if (STORE) {
+                st.row_h += act_layer;
+                st.row_c += act_layer;
+            }
 #pragma unroll
             for (int c = 0; c < KCH; ++c) x[c] = y[c];
             bias += H;
@@ -535,7 +556,7 @@ __global__ __launch_bounds__(256) void field_h3_kernel(FieldArgs a) {
 #endif
 }
 
-template <int NT>
+template <int NT, bool STORE>
 static hipError_t launch_h3_nt(const FieldArgs& a, hipStream_t stream) {
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) != hipSuccess) dev = 0;
@@ -545,23 +566,24 @@ static hipError_t launch_h3_nt(const FieldArgs& a, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {     // room for the deepest network the ABI admits
         const int max_lds = 2 * H3Lds<NT>::FRAGS * 16 + (3 * CNERF_MAX_LAYERS * NT * 32 + 2 * NT * 32 + 4 + 2 * (CNERF_MAX_LAYERS + 1) + 4) * 4;
-        if (hipError_t e = hipFuncSetAttribute((const void*)field_h3_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds)) return e;
+        if (hipError_t e = hipFuncSetAttribute((const void*)field_h3_kernel<NT, STORE>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds)) return e;
         attr_set = true;
     }
     const long long want = (a.total_tiles / a.tiles_per_image) * ((a.tiles_per_image + 3) / 4), cap = (long long)cus;
     int blocks = (int)(want < cap ? want : cap);
     if (blocks < 8) blocks = 8;
     blocks = (blocks + 7) / 8 * 8;
-    hipLaunchKernelGGL(field_h3_kernel<NT>, dim3(blocks), dim3(256), lds_bytes, stream, a);
+    hipLaunchKernelGGL((field_h3_kernel<NT, STORE>), dim3(blocks), dim3(256), lds_bytes, stream, a);
     return hipGetLastError();
 }
 
 hipError_t launch_field_h3(const FieldArgs& a, int H, hipStream_t stream) {
     if (a.n_in < 1 || a.in_level[0] < 0) return hipErrorInvalidValue;      // the cross-tile lookup prefetch assumes a volume tile first
+    const bool store = a.act_h != nullptr;      // activation-storing forward of the backward pass
     switch (H / 32) {
-        case 2: return launch_h3_nt<2>(a, stream);
-        case 4: return launch_h3_nt<4>(a, stream);
-        case 8: return launch_h3_nt<8>(a, stream);
+        case 2: return store ? launch_h3_nt<2, true>(a, stream) : launch_h3_nt<2, false>(a, stream);
+        case 4: return store ? launch_h3_nt<4, true>(a, stream) : launch_h3_nt<4, false>(a, stream);
+        case 8: return store ? launch_h3_nt<8, true>(a, stream) : launch_h3_nt<8, false>(a, stream);
         default: return hipErrorInvalidValue;
     }
 }

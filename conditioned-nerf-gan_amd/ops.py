@@ -347,8 +347,11 @@ def render_backward(net, o, levels, freq, phase, cam2world, rng, saved, grad_pix
     """Gradients of one render w.r.t. (channel-last feature volumes, freq, phase, [field parameters])."""
     B, R, S, hier = o["B"], o["R"], o["S"], o["hier"]
     dev = cam2world.device
+    # cfg: precision of the forward (the activation-storing re-run follows it); cfg32: the fp32 gradient chain
     cfg = make_cfg(net, B, levels, R, S, o["fov"], o["ray_start"], o["ray_end"], o["noise_std"], hier,
-                   o["white_back"], o["last_back"], o["clamp_mode"], precision="fp32")   # the backward is fp32
+                   o["white_back"], o["last_back"], o["clamp_mode"])
+    cfg32 = make_cfg(net, B, levels, R, S, o["fov"], o["ray_start"], o["ray_end"], o["noise_std"], hier,
+                     o["white_back"], o["last_back"], o["clamp_mode"], precision="fp32")
     if net.spec.layers[0] == "pfilm":
         c_rs, c_z, f_rs, f_z = saved[:4]
         gc = torch.empty_like(c_rs)
@@ -362,7 +365,7 @@ def render_backward(net, o, levels, freq, phase, cam2world, rng, saved, grad_pix
         return _pfilm_backward(net, cfg, levels, saved, gc, gf, hier)
     vs = volumes_struct(levels)
     packed = pack_field(net, cfg)
-    packed_t = pack_field_transposed(net, cfg)
+    packed_t = pack_field_transposed(net, cfg32)
     H, k0 = int(net.hidden_dim), int(net.input_dim)
     n_in = cfg.C // 32 + (1 if net.spec.input == "feat_xyz" else 0)
     kinds = net.spec.layers

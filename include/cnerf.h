@@ -236,7 +236,9 @@ int cnerf_merge_composite_backward(const cnerf_cfg* cfg, const float* coarse_rgb
  * image0 + n_images) of the call described by cfg.  All per-image inputs are the FULL tensors of the forward (the
  * function offsets them); grad_rgb_sigma / saved_rgb_sigma are the (B,P,S,4) tensors of that pass; grad_vols are the
  * full gradient volumes, accumulated into (zero them first).  act_* are chunk buffers for n_images images; act_feat is
- * (n, 32 * input tiles): the concatenated looked-up features (and xyz, zero padded) that layer 0 saw. */
+ * (n, 32 * input tiles): the concatenated looked-up features (and xyz, zero padded) that layer 0 saw.
+ * `packed` is in the layout of cfg->precision (the activation-storing forward runs in that precision); packed_t is always
+ * the fp32 transposed layout (the gradient chain is fp32). */
 int cnerf_field_backward(const cnerf_cfg* cfg, int32_t pass, int32_t image0, int32_t n_images, const cnerf_volumes* vols,
                          const float* packed, const float* packed_t, const float* freq, const float* phase,
                          const float* cam2world, const float* u_strat, const float* fine_z,

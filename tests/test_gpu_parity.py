@@ -301,8 +301,15 @@ def reference_grad_noise_floor(g):
     return floor
 
 
+@pytest.mark.parametrize("name", [n for n in GRAD_FIXTURES if n in SPLIT_FIXTURES])
+def test_backward_split_precision(golden, dev, name):
+    """The same gradient gate with precision = "fp16x3": forward and the activation-storing re-run of the backward in the
+    split-precision kernel (hardware sine / cosine), gradient chain and weight-gradient reduction in fp32."""
+    test_backward_teacher_forced(golden, dev, name, precision="fp16x3")
+
+
 @pytest.mark.parametrize("name", [n for n in GRAD_FIXTURES if n not in RES_FIXTURES])
-def test_backward_teacher_forced(golden, dev, name):
+def test_backward_teacher_forced(golden, dev, name, precision="fp32"):
     """Gradients of  pixels.square().mean() + depth.mean()  w.r.t. every field parameter, the mapping network, the feature
     volume and the global feature, against the reference's autograd (stored in the fixture), with the reference's fine
     depths forced (see test_render_teacher_forced).
@@ -312,6 +319,7 @@ def test_backward_teacher_forced(golden, dev, name):
     g = golden(name)
     m = g.meta
     gen = make_generator(g, dev)
+    gen.siren.precision = precision
     gen.train()
     z, vleaves, glob = make_z(g, dev, requires_grad=True)
     rng = {k: G(g.get(k), dev) for k in ("u_strat", "eps_coarse", "u_fine", "eps_final") if g.get(k) is not None}
