@@ -1,4 +1,4 @@
-// Device helpers shared by the point-pass kernels (field_kernel.hip: fp32 MFMA, field_bf6.hip: bf16x6 split).
+// Device helpers shared by the point-pass kernels (field_kernel.hip: fp32 MFMA, field_h3.hip: fp16x3 split).
 #pragma once
 #include "cnerf_dev.hpp"
 #include "cnerf_kernels.hpp"
