@@ -285,13 +285,13 @@ int cnerf_pack_field(const cnerf_cfg* cfg, const cnerf_field_params* p, float* p
         for (int l = 0; l < cfg->L; ++l) {
             const int K = (l == 0) ? pl.k0 : H;
             if (!p->w[l] || !p->b[l]) return fail(CNERF_EINVAL, "pack_field: layer %d weight/bias is NULL", l);
-            if (hipError_t e = launch_pack_h3(p->w[l], H, K, NT, wdst, inv_scale + l, wmax + l, stream)) return hip_fail(e, "pack_h3");
+            if (hipError_t e = launch_pack_h3(p->w[l], H, K, NT, l == 0, wdst, inv_scale + l, wmax + l, stream)) return hip_fail(e, "pack_h3");
             wdst += (size_t)NT * ((K + 31) / 32 * 2) * 2 * frag;
             if (hipError_t e = hipMemcpyAsync(bdst, p->b[l], H * sizeof(float), hipMemcpyDeviceToDevice, stream)) return hip_fail(e, "bias copy");
             bdst += H;
         }
         if (!p->w_final || !p->b_final) return fail(CNERF_EINVAL, "pack_field: head is NULL");
-        if (hipError_t e = launch_pack_h3(p->w_final, 4, H, 1, wdst, inv_scale + cfg->L, wmax + cfg->L, stream)) return hip_fail(e, "pack_h3");
+        if (hipError_t e = launch_pack_h3(p->w_final, 4, H, 1, false, wdst, inv_scale + cfg->L, wmax + cfg->L, stream)) return hip_fail(e, "pack_h3");
         if (hipError_t e = hipMemcpyAsync(bdst, p->b_final, 4 * sizeof(float), hipMemcpyDeviceToDevice, stream)) return hip_fail(e, "bias copy");
         bdst = packed + pl.weight_floats + pl.bias_floats;
         if (hipError_t e = launch_fill(bdst, 1.0f, H, stream)) return hip_fail(e, "fill");

@@ -68,7 +68,7 @@ __device__ __forceinline__ Split2 split8_clamped(const float* v) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// packing: fragment index ((t*KC + c)*2 + part)*64 + lane, 8 fp16 each:
+// packing: fragment index ((t*KC + c)*2 + part)*64 + lane (layer 0: (((c>>1)*OT + t)*2 + (c&1))*2 + part), 8 fp16 each:
 //   element j of lane (i = lane&31, h = lane>>5) = part_k( S * W[32t + i][16c + 8(j>>2) + 4h + (j&3)] )
 // S = 2^floor(log2(16384 / max|W|)) per matrix (on the device, no host round trip); 1/S goes to the kernel.
 // ---------------------------------------------------------------------------------------------------------------
@@ -88,7 +88,7 @@ __device__ __forceinline__ float pow2_scale(float wmax) {
     return ldexpf(1.0f, e);
 }
 
-__global__ void pack_h3_kernel(const float* __restrict__ w, int n_out, int K_real, int KC, int OT, const uint32_t* wmax_slot,
+__global__ void pack_h3_kernel(const float* __restrict__ w, int n_out, int K_real, int KC, int OT, int k_outer, const uint32_t* wmax_slot,
                                float* inv_scale_slot, _Float16* __restrict__ dst) {
     const float S = pow2_scale(__uint_as_float(*wmax_slot));
     if (blockIdx.x == 0 && threadIdx.x == 0) *inv_scale_slot = 1.0f / S;
@@ -102,13 +102,16 @@ __global__ void pack_h3_kernel(const float* __restrict__ w, int n_out, int K_rea
         const float v = (row < n_out && col < K_real) ? w[(size_t)row * K_real + col] * S : 0.0f;
         const _Float16 a0 = (_Float16)v;
         const _Float16 a1 = (_Float16)(v - (float)a0);
-        const size_t base = ((size_t)tc * 2) * 64 * 8 + (size_t)lane * 8 + j;
+        // fragment pair index: (t, c) row-major, or -- layer 0 -- input tile outermost so that the two chunks of one input tile
+        // for all output tiles form one contiguous weight unit
+        const size_t pair = k_outer ? ((size_t)(c >> 1) * OT + t) * 2 + (c & 1) : (size_t)tc;
+        const size_t base = (pair * 2) * 64 * 8 + (size_t)lane * 8 + j;
         dst[base] = a0;
         dst[base + 64 * 8] = a1;
     }
 }
 
-hipError_t launch_pack_h3(const float* w, int n_out, int K_real, int OT, void* dst, float* inv_scale_slot, float* wmax_slot,
+hipError_t launch_pack_h3(const float* w, int n_out, int K_real, int OT, bool k_outer, void* dst, float* inv_scale_slot, float* wmax_slot,
                           hipStream_t stream) {
     if (hipError_t e = hipMemsetAsync(wmax_slot, 0, sizeof(float), stream)) return e;
     const long long n = (long long)n_out * K_real;
@@ -119,7 +122,7 @@ hipError_t launch_pack_h3(const float* w, int n_out, int K_real, int OT, void* d
     const long long total = (long long)OT * KC * 64 * 8;
     long long blocks = (total + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(pack_h3_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, w, n_out, K_real, KC, OT, (const uint32_t*)wmax_slot,
+    hipLaunchKernelGGL(pack_h3_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, w, n_out, K_real, KC, OT, k_outer ? 1 : 0, (const uint32_t*)wmax_slot,
                        inv_scale_slot, (_Float16*)dst);
     return hipGetLastError();
 }
@@ -204,6 +207,13 @@ __device__ __forceinline__ void film_split(const f32x16& acc, float inv_s, const
 // ---------------------------------------------------------------------------------------------------------------
 // weight units
 // ---------------------------------------------------------------------------------------------------------------
+// Weight units in flight: SLOTS LDS buffers, one barrier per SLOTS / 2 units (2: a barrier per unit).  Measured: halving
+// the barriers (-DCNERF_H3_SLOTS=4, 128 KiB of LDS) changes nothing (11.24 vs 11.21 ms per launch): the four waves arrive
+// together, the barrier is not where the time goes.  Default: two slots.
+#ifndef CNERF_H3_SLOTS
+#define CNERF_H3_SLOTS 2
+#endif
+
 template <int NT>
 struct H3Lds {
     static constexpr int KC = 2 * NT;
@@ -220,7 +230,7 @@ __device__ __forceinline__ void dma_piece(const f16x8* src_lane, f16x8* lds_dst)
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, OFF, 0);
 }
 
-// hidden / head unit (and the layer-0 unit of a single-input network): contiguous in the packed stream; wave w moves the
+// every weight unit is contiguous in the packed stream (pack_h3_kernel); wave w moves the
 // pieces [w*PER_WAVE, (w+1)*PER_WAVE), four per base address (instruction offsets 0, 1, 2, 3 KiB)
 template <int NT>
 __device__ __forceinline__ void dma_unit_flat(const f16x8* __restrict__ src, f16x8* lds_dst, int wave_u, int lane) {
@@ -237,18 +247,6 @@ __device__ __forceinline__ void dma_unit_flat(const f16x8* __restrict__ src, f16
         if (4 * q + 3 < PW) dma_piece<3072>(sq, dq);
     }
 }
-// layer-0 unit of input tile tk of a multi-input network: piece (t, c, part) comes from fragment ((t*KC0 + 2 tk + c)*2 + part)
-template <int NT>
-__device__ __forceinline__ void dma_unit_layer0(const f16x8* __restrict__ w0, int KC0, int tk, f16x8* lds_dst, int wave_u, int lane) {
-    if (KC0 == 2) return dma_unit_flat<NT>(w0, lds_dst, wave_u, lane);
-#pragma unroll 1
-    for (int i = 0; i < H3Lds<NT>::PER_WAVE; ++i) {
-        const int piece = wave_u * H3Lds<NT>::PER_WAVE + i;
-        const int k = piece & 1, tc = piece >> 1, c = tc & 1, t = tc >> 1;
-        dma_piece<0>(w0 + ((size_t)(t * KC0 + 2 * tk + c) * 2 + k) * 64 + lane, lds_dst + piece * 64);
-    }
-}
-
 #define H3_MFMA3(acc, a, xs)                                                                  \
     do {                                                                                       \
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], (xs).frag(0), acc, 0, 0, 0);        \
@@ -345,7 +343,9 @@ __device__ __forceinline__ TilePoint tile_of_group(const FieldArgs& a, long long
     return p;
 }
 
-template <int NT, bool STORE>
+// PAIRED: four LDS slots, one barrier per TWO weight units (single-input networks: the unit's parity inside the tile is then
+// static in the unrolled loops); otherwise two slots and a barrier per unit.
+template <int NT, bool STORE, bool PAIRED>
 __global__ __launch_bounds__(256) void field_h3_kernel(FieldArgs a) {
 #ifdef CNERF_STAMPS
     unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -355,9 +355,9 @@ __global__ __launch_bounds__(256) void field_h3_kernel(FieldArgs a) {
     constexpr int UNIT_FR = H3Lds<NT>::FRAGS;
     constexpr int H = NT * 32;
     constexpr int KCH = 2 * NT;
-    constexpr size_t FR = 64;
-    f16x8* lds = reinterpret_cast<f16x8*>(smem);                                    // two weight units
-    float* lds_bias = reinterpret_cast<float*>(smem + 2 * (size_t)UNIT_FR * 16);    // biases, head bias, 1/S per matrix, ones, zeros
+    constexpr int SLOTS = PAIRED ? 4 : 2, PERIOD = SLOTS / 2;
+    f16x8* lds = reinterpret_cast<f16x8*>(smem);                                    // SLOTS weight units
+    float* lds_bias = reinterpret_cast<float*>(smem + SLOTS * (size_t)UNIT_FR * 16);   // biases, head bias, 1/S per matrix, ones, zeros
     const float* lds_ones = lds_bias + a.bias_floats;
     const float* lds_zeros = lds_ones + H;
     float* lds_freq = lds_bias + a.bias_floats + 2 * H;                             // FiLM vectors of the block's image
@@ -377,17 +377,38 @@ __global__ __launch_bounds__(256) void field_h3_kernel(FieldArgs a) {
     const int blk_per_cls = (nblk + 7 - cls) / 8;
     const long long g_begin = total_groups * cls / 8 + idx_in_cls, g_end = total_groups * (cls + 1) / 8;
 
-    const int KC0 = 2 * a.n_in;
-    const f16x8* w_layer0 = reinterpret_cast<const f16x8*>(a.packed);
-    const f16x8* w_seq = w_layer0 + (size_t)NT * KC0 * 2 * FR;       // hidden unit 0 of the flat sequence
-    int cur = 0;                                                     // LDS half holding the current weight unit
+    const f16x8* w_units = reinterpret_cast<const f16x8*>(a.packed);  // the per-tile unit sequence, back to back
     int staged_b = -1;                                               // image whose FiLM vectors are in LDS
     if (g_begin >= g_end) return;                                    // block-uniform
 
-    // prologue: biases and scales into LDS, weight unit 0 (layer 0, input tile 0) into half 0 (the first barrier publishes
-    // both); position and lookups of the first tile
+    // The block consumes one flat sequence of weight units: n_units per point tile (layer-0 unit per input tile, NT per
+    // hidden layer, head), tile after tile.  Unit i lives in LDS slot i % SLOTS; every PERIOD units one barrier publishes
+    // the PERIOD units copied during the previous period and frees the slots of the period before for the next copies.
+    const int n_units = a.n_in + (a.L - 1) * NT + 1;                // >= 2; even when PAIRED (n_in == 1)
+    int dma_k = 0, dma_slot = 0;                                     // next unit to copy (index in the tile sequence), its slot
+    int use_slot = 0;                                                // slot of the next unit to consume
+    auto dma_next = [&]() {       // (past the block's last tile this re-copies units nobody reads: harmless, drained at the end)
+        dma_unit_flat<NT>(w_units + (size_t)dma_k * UNIT_FR, lds + dma_slot * UNIT_FR, wave_u, lane);
+        dma_k = dma_k + 1 == n_units ? 0 : dma_k + 1;
+        dma_slot = (dma_slot + 1) & (SLOTS - 1);
+    };
+    // every wave, at the start of every unit; `first_of_period` is a compile-time fact at every call site
+    auto unit_begin = [&](bool first_of_period) -> const f16x8* {
+        if (first_of_period) {
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < PERIOD; ++i) dma_next();
+        }
+        const f16x8* unit = lds + use_slot * UNIT_FR;
+        use_slot = (use_slot + 1) & (SLOTS - 1);
+        return unit;
+    };
+
+    // prologue: biases and scales into LDS, the first PERIOD weight units (the first barrier publishes both); position and
+    // lookups of the first tile
     for (int i = threadIdx.x; i < a.bias_floats + 2 * H; i += 256) lds_bias[i] = a.bias[i];
-    dma_unit_layer0<NT>(w_layer0, KC0, 0, lds, wave_u, lane);
+#pragma unroll
+    for (int i = 0; i < PERIOD; ++i) dma_next();
     TilePoint tp = tile_of_group(a, g_begin, G, wave, j);
     float px, py, pz;
     tile_point(a, tp.b, tp.nn, tp.valid, h, true, px, py, pz);
@@ -405,7 +426,8 @@ __global__ __launch_bounds__(256) void field_h3_kernel(FieldArgs a) {
                 lds_freq[i] = a.freq[(size_t)b * a.film_stride + i];
                 lds_phase[i] = a.phase[(size_t)b * a.film_stride + i];
             }
-            staged_b = b;                                           // published by the unit barrier below
+            staged_b = b;
+            __syncthreads();                                        // (once per image: not every unit starts with a barrier)
         }
         // raw sample coordinate of the NEXT tile: one load now, consumed behind the head's barrier
         const bool has_next = g + blk_per_cls < g_end;
@@ -436,9 +458,7 @@ __global__ __launch_bounds__(256) void field_h3_kernel(FieldArgs a) {
 #else
                 if (tk > 0) input_tile_issue(a, b, tk, px, py, pz, h, it);   // tile 0 was issued during the previous head
 #endif
-                __syncthreads();                                    // unit `tk` has landed; the other half is free
-                if (tk + 1 < a.n_in) dma_unit_layer0<NT>(w_layer0, KC0, tk + 1, lds + (cur ^ 1) * UNIT_FR, wave_u, lane);
-                else dma_unit_flat<NT>(w_seq, lds + (cur ^ 1) * UNIT_FR, wave_u, lane);
+                const f16x8* unit = unit_begin(true);               // PAIRED: n_in == 1, unit 0 of the tile
                 const f32x16 feat = input_tile_reduce(it, px, py, pz, h);
                 float fv[16];
 #pragma unroll
@@ -451,8 +471,7 @@ __global__ __launch_bounds__(256) void field_h3_kernel(FieldArgs a) {
                 Split2 f2[2];
                 f2[0] = split8_clamped(fv);
                 f2[1] = split8_clamped(fv + 8);
-                h3_layer0_from_lds<NT>(lds + cur * UNIT_FR, f2, acc0, lane);
-                cur ^= 1;
+                h3_layer0_from_lds<NT>(unit, f2, acc0, lane);
             }
             BSTAMP(2);
             const bool film = a.layer_kind[0] == CNERF_LAYER_FILM;
@@ -471,7 +490,6 @@ __global__ __launch_bounds__(256) void field_h3_kernel(FieldArgs a) {
         }
         BSTAMP(3);
         // ---- hidden layers: NT weight units each ----------------------------------------------------------------------
-        int seq = 0;
         for (int l = 1; l < a.L; ++l) {
             const bool film = a.layer_kind[l] == CNERF_LAYER_FILM;
             const float* fr_l = film ? lfr : lds_ones;
@@ -481,12 +499,11 @@ __global__ __launch_bounds__(256) void field_h3_kernel(FieldArgs a) {
             FilmPair fp;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                __syncthreads();                               // weight unit `seq` has landed; the other half is free
-                dma_unit_flat<NT>(w_seq + (size_t)(seq + 1) * UNIT_FR, lds + (cur ^ 1) * UNIT_FR, wave_u, lane);
+                const f16x8* unit = unit_begin(!PAIRED || (t & 1));   // PAIRED: unit 1 + (l-1) NT + t of the tile, even iff t is odd
                 f32x16 acc;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-                acc = h3_tile_from_lds<NT, 7>(lds + cur * UNIT_FR, x, acc, lane, [&](int c) {
+                acc = h3_tile_from_lds<NT, 7>(unit, x, acc, lane, [&](int c) {
                     if (t > 0 && c < 16) {                     // epilogue of tile t-1, one pair of elements per two chunks
                         if (!(c & 1)) fp = film_pair_load(bias, fr_l, ph_l, t - 1, h, c);
                         else film_split_pair<STORE>(acc_prev, inv_s, fp, t - 1, h, c - 1, &y[2 * (t - 1)], st);
@@ -498,8 +515,6 @@ __global__ __launch_bounds__(256) void field_h3_kernel(FieldArgs a) {
                         film_split_pair<STORE>(acc_prev, inv_s, film_pair_load(bias, fr_l, ph_l, t - 1, h, r), t - 1, h, r, &y[2 * (t - 1)], st);
                 }
                 acc_prev = acc;
-                cur ^= 1;
-                ++seq;
             }
             film_split<STORE>(acc_prev, inv_s, bias, fr_l, ph_l, NT - 1, h, &y[2 * (NT - 1)], st);
             if (STORE) {
@@ -518,8 +533,7 @@ __global__ __launch_bounds__(256) void field_h3_kernel(FieldArgs a) {
         // ---- head (last unit of the sequence).  Behind its barrier: layer-0 unit 0 streams in for the next group, the
         // next tile's position is finished and its 32 lookups are issued -- they fly under the head's MFMAs.
         {
-            __syncthreads();
-            if (has_next) dma_unit_layer0<NT>(w_layer0, KC0, 0, lds + (cur ^ 1) * UNIT_FR, wave_u, lane);
+            const f16x8* unit = unit_begin(!PAIRED);                  // PAIRED: unit 1 + (L-1) NT of the tile, odd
             float nx, ny, nz;                                   // without a next group: this tile again (harmless, keeps `it` dead above)
             tile_point_finish(a, tn.b, tn.nn, raw_next, tn.valid, h, has_next, nx, ny, nz);
 #ifndef CNERF_H3_NOPREFETCH
@@ -528,8 +542,7 @@ __global__ __launch_bounds__(256) void field_h3_kernel(FieldArgs a) {
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-            acc = h3_tile_from_lds<NT, 0>(lds + cur * UNIT_FR, x, acc, lane, [](int) {});
-            cur ^= 1;
+            acc = h3_tile_from_lds<NT, 0>(unit, x, acc, lane, [](int) {});
             if (valid && h == 0) {
                 const f32x4 hb = *reinterpret_cast<const f32x4*>(bias);
                 const float inv_s = lds_inv_s[a.L];
@@ -550,31 +563,46 @@ __global__ __launch_bounds__(256) void field_h3_kernel(FieldArgs a) {
         }
         BSTAMP(5);
     }
+    __syncthreads();                                                 // drain the copies issued for tiles this block does not have
 #ifdef CNERF_STAMPS
     if (a.stamps && lane == 0)
         for (int i = 0; i < 8; ++i) atomicAdd(a.stamps + i, st_[i]);
 #endif
 }
 
-template <int NT, bool STORE>
-static hipError_t launch_h3_nt(const FieldArgs& a, hipStream_t stream) {
+constexpr size_t LDS_LIMIT = 160 * 1024;
+
+template <int NT>
+static size_t h3_lds_bytes(const FieldArgs& a, int slots) {
+    // weight units (32 KiB each at H = 256), biases + scales, ones / zeros, freq / phase of one image
+    return slots * (size_t)H3Lds<NT>::FRAGS * 16 + ((size_t)a.bias_floats + 2 * NT * 32 + 2 * (size_t)a.film_stride) * 4;
+}
+
+template <int NT, bool STORE, bool PAIRED>
+static hipError_t launch_h3_inst(const FieldArgs& a, hipStream_t stream) {
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) != hipSuccess) dev = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
-    // 64 KiB of weight units at H = 256, biases + scales, freq / phase of one image
-    const size_t lds_bytes = 2 * (size_t)H3Lds<NT>::FRAGS * 16 + ((size_t)a.bias_floats + 2 * NT * 32 + 2 * (size_t)a.film_stride) * 4;
+    const size_t lds_bytes = h3_lds_bytes<NT>(a, PAIRED ? 4 : 2);
+    if (lds_bytes > LDS_LIMIT) return hipErrorInvalidValue;
     static bool attr_set = false;
-    if (!attr_set) {     // room for the deepest network the ABI admits
-        const int max_lds = 2 * H3Lds<NT>::FRAGS * 16 + (3 * CNERF_MAX_LAYERS * NT * 32 + 2 * NT * 32 + 4 + 2 * (CNERF_MAX_LAYERS + 1) + 4) * 4;
-        if (hipError_t e = hipFuncSetAttribute((const void*)field_h3_kernel<NT, STORE>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds)) return e;
+    if (!attr_set) {
+        if (hipError_t e = hipFuncSetAttribute((const void*)field_h3_kernel<NT, STORE, PAIRED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT)) return e;
         attr_set = true;
     }
     const long long want = (a.total_tiles / a.tiles_per_image) * ((a.tiles_per_image + 3) / 4), cap = (long long)cus;
     int blocks = (int)(want < cap ? want : cap);
     if (blocks < 8) blocks = 8;
     blocks = (blocks + 7) / 8 * 8;
-    hipLaunchKernelGGL((field_h3_kernel<NT, STORE>), dim3(blocks), dim3(256), lds_bytes, stream, a);
+    hipLaunchKernelGGL((field_h3_kernel<NT, STORE, PAIRED>), dim3(blocks), dim3(256), lds_bytes, stream, a);
     return hipGetLastError();
+}
+
+template <int NT, bool STORE>
+static hipError_t launch_h3_nt(const FieldArgs& a, hipStream_t stream) {
+    // one barrier per two weight units where the unit parity is static (single-input networks) and four slots fit in LDS
+    if (CNERF_H3_SLOTS == 4 && a.n_in == 1 && h3_lds_bytes<NT>(a, 4) <= LDS_LIMIT) return launch_h3_inst<NT, STORE, true>(a, stream);
+    return launch_h3_inst<NT, STORE, false>(a, stream);
 }
 
 hipError_t launch_field_h3(const FieldArgs& a, int H, hipStream_t stream) {
