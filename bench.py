@@ -291,7 +291,11 @@ def main():
         roof = {"kernel": "field_tile_kernel<8> (sample + trilinear lookup + FiLM-SIREN MLP, fp32 MFMA)",
                 "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None}
+    # HBM bytes are not measurable from inside this process: `traffic` stays null here; the rocprofv3 PMC passes
+    # (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, profiles/r01_field_kernel_profile.md) give 97 MB per launch at batch 2 for the
+    # fp32 kernel -- the two 33.5 MB channel-last volumes read once, rgb_sigma and z written once -- against 0.86 TFLOP.
     roof.update({"avg_launch_ms": avg_ms, "launches": len(kern_ms), "flops_per_launch": flops_per_launch,
+                 "traffic_pmc_reference": "profiles/r01_field_kernel_profile.md (97 MB per launch at batch 2, fp32 kernel)",
                  "share_of_step": 2 * avg_ms / (elapsed / args.steps * 1e3)})
 
     if rank == 0:
