@@ -107,7 +107,7 @@ def sample_composite_pass(args, gen, fvol, glob, cam, meta, evs):
     B, R, S = args.batch, args.img_size, args.num_steps
     aux = {}
     with torch.no_grad():
-        gen((fvol, glob), cam, R, FOV, RAY_START, RAY_END, S, _aux=aux, **meta)
+        gen(zin(gen, fvol, glob), cam, R, FOV, RAY_START, RAY_END, S, _aux=aux, **meta)
         fcl = ops.channel_last(fvol)
         pts = torch.cat([aux["coarse_points"].reshape(B, -1, 3), aux["fine_points"].reshape(B, -1, 3)], 1).contiguous()
         allz = torch.cat([aux["fine_z"], aux["coarse_z"]], -1)
@@ -140,6 +140,11 @@ def sample_composite_pass(args, gen, fvol, glob, cam, meta, evs):
             "note": "effective bandwidth: neighbouring samples share corner lines in L2 / Infinity Cache (SURVEY.md 8d)"}
 
 
+def zin(gen, fvol, glob):
+    """The generator's `z`: (feature volume, global feature) for the globally conditioned families, the volume alone otherwise."""
+    return (fvol, glob) if gen.siren.spec.has_global else fvol
+
+
 def fast_path(args, gen, fvol, glob, cam, meta, evs):
     """Secondary measurement (not `value`): the same step with precision = "fp16x3" -- every fp32 product evaluated as three
     fp16 MFMAs (fp32 accumulate) on two-way fp16 splits of both operands.  Same parity gates as the fp32 path
@@ -152,11 +157,11 @@ def fast_path(args, gen, fvol, glob, cam, meta, evs):
     try:
         with torch.no_grad():
             for _ in range(2):
-                gen((fvol, glob), cam, R, FOV, RAY_START, RAY_END, S, **meta)
+                gen(zin(gen, fvol, glob), cam, R, FOV, RAY_START, RAY_END, S, **meta)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for i in range(steps):
-                gen((fvol, glob), cam, R, FOV, RAY_START, RAY_END, S, _field_events=events[4 * i:4 * i + 4], **meta)
+                gen(zin(gen, fvol, glob), cam, R, FOV, RAY_START, RAY_END, S, _field_events=events[4 * i:4 * i + 4], **meta)
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / steps
     finally:
@@ -262,7 +267,7 @@ def main():
         ev = events[4 * i:4 * i + 4] if i is not None else None
         cnerf_amd.ops._pack_cache.clear()                     # training changes the weights every step: re-pack
         with torch.no_grad():
-            return gen((fvol, glob), cam, R, FOV, RAY_START, RAY_END, S, _field_events=ev, **meta)
+            return gen(zin(gen, fvol, glob), cam, R, FOV, RAY_START, RAY_END, S, _field_events=ev, **meta)
 
     last = {}
 

@@ -56,8 +56,8 @@ int check_cfg(const cnerf_cfg* c, bool need_render) {
     if (c->precision != CNERF_PREC_FP32 && c->precision != CNERF_PREC_FP16X3) return fail(CNERF_EINVAL, "precision=%d unknown", c->precision);
     if (c->precision == CNERF_PREC_FP16X3)
         for (int l = 0; l < c->L; ++l)
-            if (c->layer_kind[l] != CNERF_LAYER_FILM && c->layer_kind[l] != CNERF_LAYER_SINE)
-                return fail(CNERF_EINVAL, "precision fp16x3 supports FiLM and plain-sine layers only");
+            if (c->layer_kind[l] == CNERF_LAYER_PFILM)
+                return fail(CNERF_EINVAL, "precision fp16x3 does not cover the per-point FiLM family");
     if (need_render) {
         if (c->R < 1 || c->R > 4096) return fail(CNERF_EINVAL, "R=%d out of range [1,4096]", c->R);
         if (c->S < 2 || c->S > 128) return fail(CNERF_EINVAL, "S=%d out of range [2,128]", c->S);
@@ -103,14 +103,17 @@ PackedLayout packed_layout(const cnerf_cfg* c) {
         // fp16 fragments: (t, k-chunk of 16, part) x 64 lanes x 8 fp16 = 256 floats' worth of bytes per (t, c, part);
         // behind the biases: 1/S of every matrix (L + 1), then the max|W| scratch slots (L + 1), padded to 4 floats
         const size_t frag = 64 * 8 / 2;   // in floats
+        size_t mats = 0;
         for (int l = 0; l < c->L; ++l) {
             const size_t kc = (l == 0) ? 2 * (size_t)p.n_in : 2 * NT;
-            p.weight_floats += NT * kc * 2 * frag;
-            p.bias_floats += c->H;
+            const size_t n = c->layer_kind[l] == CNERF_LAYER_RES ? 2 : 1;      // residual block: fc1 and fc2
+            p.weight_floats += n * NT * kc * 2 * frag;
+            p.bias_floats += n * c->H;
+            mats += n;
             if (c->layer_kind[l] == CNERF_LAYER_FILM) p.n_film++;
         }
         p.weight_floats += 1 * 2 * NT * 2 * frag;   // head, one 32-row tile
-        p.bias_floats += 4 + (2 * ((size_t)c->L + 1) + 3) / 4 * 4;
+        p.bias_floats += 4 + (2 * (mats + 1) + 3) / 4 * 4;
         return p;
     }
     for (int l = 0; l < c->L; ++l) {
@@ -179,6 +182,8 @@ int fill_field_args(FieldArgs& a, const cnerf_cfg* c, const cnerf_volumes* vols,
     a.geom = make_geom(c);
     a.half_voxel = c->voxel_length / 2.0f;
     a.L = c->L;
+    a.n_mats = 0;
+    for (int l = 0; l < c->L; ++l) a.n_mats += c->layer_kind[l] == CNERF_LAYER_RES ? 2 : 1;
     a.flags = c->flags;
     for (int l = 0; l < c->L; ++l) a.layer_kind[l] = c->layer_kind[l];
     return CNERF_OK;
@@ -280,18 +285,28 @@ int cnerf_pack_field(const cnerf_cfg* cfg, const cnerf_field_params* p, float* p
     }
     if (cfg->precision == CNERF_PREC_FP16X3) {
         const size_t frag = 64 * 8 / 2;
-        float* inv_scale = packed + pl.weight_floats + (size_t)cfg->L * H + 4;   // 1/S per matrix, then the max|W| scratch
-        float* wmax = inv_scale + cfg->L + 1;
+        int mats = 0;
+        for (int l = 0; l < cfg->L; ++l) mats += cfg->layer_kind[l] == CNERF_LAYER_RES ? 2 : 1;
+        float* inv_scale = packed + pl.weight_floats + (size_t)mats * H + 4;     // 1/S per matrix and the head's, then the max|W| scratch
+        float* wmax = inv_scale + mats + 1;
+        int m = 0;
         for (int l = 0; l < cfg->L; ++l) {
             const int K = (l == 0) ? pl.k0 : H;
+            const bool res = cfg->layer_kind[l] == CNERF_LAYER_RES;
             if (!p->w[l] || !p->b[l]) return fail(CNERF_EINVAL, "pack_field: layer %d weight/bias is NULL", l);
-            if (hipError_t e = launch_pack_h3(p->w[l], H, K, NT, l == 0, wdst, inv_scale + l, wmax + l, stream)) return hip_fail(e, "pack_h3");
-            wdst += (size_t)NT * ((K + 31) / 32 * 2) * 2 * frag;
-            if (hipError_t e = hipMemcpyAsync(bdst, p->b[l], H * sizeof(float), hipMemcpyDeviceToDevice, stream)) return hip_fail(e, "bias copy");
-            bdst += H;
+            if (res && (!p->w2[l] || !p->b2[l])) return fail(CNERF_EINVAL, "pack_field: residual layer %d fc2 is NULL", l);
+            for (int half = 0; half < (res ? 2 : 1); ++half) {
+                const float* w = half ? p->w2[l] : p->w[l];
+                const float* b = half ? p->b2[l] : p->b[l];
+                if (hipError_t e = launch_pack_h3(w, H, K, NT, l == 0, wdst, inv_scale + m, wmax + m, stream)) return hip_fail(e, "pack_h3");
+                wdst += (size_t)NT * ((K + 31) / 32 * 2) * 2 * frag;
+                if (hipError_t e = hipMemcpyAsync(bdst, b, H * sizeof(float), hipMemcpyDeviceToDevice, stream)) return hip_fail(e, "bias copy");
+                bdst += H;
+                ++m;
+            }
         }
         if (!p->w_final || !p->b_final) return fail(CNERF_EINVAL, "pack_field: head is NULL");
-        if (hipError_t e = launch_pack_h3(p->w_final, 4, H, 1, false, wdst, inv_scale + cfg->L, wmax + cfg->L, stream)) return hip_fail(e, "pack_h3");
+        if (hipError_t e = launch_pack_h3(p->w_final, 4, H, 1, false, wdst, inv_scale + m, wmax + m, stream)) return hip_fail(e, "pack_h3");
         if (hipError_t e = hipMemcpyAsync(bdst, p->b_final, 4 * sizeof(float), hipMemcpyDeviceToDevice, stream)) return hip_fail(e, "bias copy");
         bdst = packed + pl.weight_floats + pl.bias_floats;
         if (hipError_t e = launch_fill(bdst, 1.0f, H, stream)) return hip_fail(e, "fill");

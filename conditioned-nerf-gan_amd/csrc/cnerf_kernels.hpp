@@ -50,6 +50,7 @@ struct FieldArgs {
     RayGeom geom;
     float half_voxel;
     int L;
+    int n_mats;              // weight matrices before the head (a residual block counts two)
     int film_stride;
     int bias_floats;         // biases of all layers + head (padded to 4): ones[H], zeros[H] follow
     uint32_t flags;

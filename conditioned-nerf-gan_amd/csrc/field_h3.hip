@@ -157,12 +157,24 @@ struct ActStore {
 // two), FiLM with product and sum rounded separately like the reference (a plain sine layer runs with freq = 1,
 // phase = 0, which is exact -- one branch-free code path), sine, split into the fragments of the chunk pair `out2`
 // (element r of the tile is element r & 7 of chunk r >> 3).  Pairs of a tile must arrive in order r = 0, 2, 4, ...
-template <bool STORE>
+// the two fp16 halves of a packed pair, widened (exact)
+__device__ __forceinline__ float half_lo(uint32_t u) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(u & 0xffffu)); }
+__device__ __forceinline__ float half_hi(uint32_t u) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(u >> 16)); }
+
+// RESID (second matrix of a residual block, siren.py:218-230): the slot the result goes to still holds the block's input
+// x as its two fp16 parts; x = hi + lo is added to W2 y + b2 before the sine, and the slot is overwritten.
+template <bool STORE, bool RESID>
 __device__ __forceinline__ void film_split_pair(const f32x16& acc, float inv_s, const FilmPair& f, int t, int h, int r, Split2* out2,
                                                 ActStore& st) {
     float a0 = __builtin_fmaf(acc[r], inv_s, f.bs[0]), a1 = __builtin_fmaf(acc[r + 1], inv_s, f.bs[1]);
-    a0 = f.fr[0] * a0 + f.ph[0];
-    a1 = f.fr[1] * a1 + f.ph[1];
+    if (RESID) {
+        const uint32_t xh = out2[r >> 3].p[0][(r & 7) >> 1], xl = out2[r >> 3].p[1][(r & 7) >> 1];
+        a0 = (half_lo(xh) + half_lo(xl)) + a0;
+        a1 = (half_hi(xh) + half_hi(xl)) + a1;
+    } else {
+        a0 = f.fr[0] * a0 + f.ph[0];
+        a1 = f.fr[1] * a1 + f.ph[1];
+    }
     float v0, v1;
     if (STORE) {
         float c0, c1;
@@ -192,7 +204,7 @@ __device__ __forceinline__ void film_split_pair(const f32x16& acc, float inv_s, 
 }
 
 // whole tile at once (layer 0 and the last output tile of a layer), FiLM pairs fetched one step ahead
-template <bool STORE>
+template <bool STORE, bool RESID>
 __device__ __forceinline__ void film_split(const f32x16& acc, float inv_s, const float* lbias, const float* lfr, const float* lph, int t,
                                            int h, Split2* out2, ActStore& st) {
     FilmPair f = film_pair_load(lbias, lfr, lph, t, h, 0);
@@ -200,7 +212,7 @@ __device__ __forceinline__ void film_split(const f32x16& acc, float inv_s, const
     for (int r = 0; r < 16; r += 2) {
         const FilmPair fcur = f;
         if (r + 2 < 16) f = film_pair_load(lbias, lfr, lph, t, h, r + 2);
-        film_split_pair<STORE>(acc, inv_s, fcur, t, h, r, out2, st);
+        film_split_pair<STORE, RESID>(acc, inv_s, fcur, t, h, r, out2, st);
     }
 }
 
@@ -328,6 +340,9 @@ __device__ __forceinline__ void h3_layer0_from_lds(const f16x8* lds_unit, const 
 #define BSTAMP(i)
 #endif
 
+struct ResidNo { static constexpr bool value = false; };      // compile-time tags for the `matrix` lambda of the kernel
+struct ResidYes { static constexpr bool value = true; };
+
 // the point a wave works on: group g of 4 consecutive tiles of one image, tile `wave` of the group
 struct TilePoint {
     int b;
@@ -345,7 +360,7 @@ __device__ __forceinline__ TilePoint tile_of_group(const FieldArgs& a, long long
 
 // PAIRED: four LDS slots, one barrier per TWO weight units (single-input networks: the unit's parity inside the tile is then
 // static in the unrolled loops); otherwise two slots and a barrier per unit.
-template <int NT, bool STORE, bool PAIRED>
+template <int NT, bool STORE, bool PAIRED, bool HAS_RES>
 __global__ __launch_bounds__(256) void field_h3_kernel(FieldArgs a) {
 #ifdef CNERF_STAMPS
     unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -362,7 +377,7 @@ __global__ __launch_bounds__(256) void field_h3_kernel(FieldArgs a) {
     const float* lds_zeros = lds_ones + H;
     float* lds_freq = lds_bias + a.bias_floats + 2 * H;                             // FiLM vectors of the block's image
     float* lds_phase = lds_freq + a.film_stride;
-    const float* lds_inv_s = lds_bias + (size_t)a.L * H + 4;
+    const float* lds_inv_s = lds_bias + (size_t)a.n_mats * H + 4;    // 1/S per matrix (a residual block has two), then the head's
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -384,7 +399,7 @@ __global__ __launch_bounds__(256) void field_h3_kernel(FieldArgs a) {
     // The block consumes one flat sequence of weight units: n_units per point tile (layer-0 unit per input tile, NT per
     // hidden layer, head), tile after tile.  Unit i lives in LDS slot i % SLOTS; every PERIOD units one barrier publishes
     // the PERIOD units copied during the previous period and frees the slots of the period before for the next copies.
-    const int n_units = a.n_in + (a.L - 1) * NT + 1;                // >= 2; even when PAIRED (n_in == 1)
+    const int n_units = a.n_in + (a.n_mats - 1) * NT + 1;           // >= 2; even when PAIRED (n_in == 1)
     int dma_k = 0, dma_slot = 0;                                     // next unit to copy (index in the tile sequence), its slot
     int use_slot = 0;                                                // slot of the next unit to consume
     auto dma_next = [&]() {       // (past the block's last tile this re-copies units nobody reads: harmless, drained at the end)
@@ -477,7 +492,7 @@ __global__ __launch_bounds__(256) void field_h3_kernel(FieldArgs a) {
             const bool film = a.layer_kind[0] == CNERF_LAYER_FILM;
             const float inv_s = lds_inv_s[0];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) film_split<STORE>(acc0[t], inv_s, bias, film ? lfr : lds_ones, film ? lph : lds_zeros, t, h, &x[2 * t], st);
+            for (int t = 0; t < NT; ++t) film_split<STORE, false>(acc0[t], inv_s, bias, film ? lfr : lds_ones, film ? lph : lds_zeros, t, h, &x[2 * t], st);
             if (STORE) {
                 st.row_h += act_layer;
                 st.row_c += act_layer;
@@ -489,51 +504,64 @@ __global__ __launch_bounds__(256) void field_h3_kernel(FieldArgs a) {
             }
         }
         BSTAMP(3);
-        // ---- hidden layers: NT weight units each ----------------------------------------------------------------------
-        for (int l = 1; l < a.L; ++l) {
-            const bool film = a.layer_kind[l] == CNERF_LAYER_FILM;
-            const float* fr_l = film ? lfr : lds_ones;
-            const float* ph_l = film ? lph : lds_zeros;
-            const float inv_s = lds_inv_s[l];
+        // ---- hidden layers: NT weight units per matrix -------------------------------------------------------------------
+        // One matrix: out[t] = epilogue(W[t] in) for the NT output tiles, the epilogue of tile t-1 pipelined under the MFMAs
+        // of tile t.  RESID: `out` is the residual block's input x and is updated in place.
+        int m = 1;                                                   // matrix counter (scales, activation slabs)
+        auto matrix = [&](const Split2* in, Split2* out, auto resid_tag, const float* fr_l, const float* ph_l) {
+            constexpr bool RESID = decltype(resid_tag)::value;
+            const float inv_s = lds_inv_s[m];
             f32x16 acc_prev;
             FilmPair fp;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                const f16x8* unit = unit_begin(!PAIRED || (t & 1));   // PAIRED: unit 1 + (l-1) NT + t of the tile, even iff t is odd
+                const f16x8* unit = unit_begin(!PAIRED || (t & 1));   // PAIRED: unit 1 + (m-1) NT + t of the tile, even iff t is odd
                 f32x16 acc;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-                acc = h3_tile_from_lds<NT, 7>(unit, x, acc, lane, [&](int c) {
+                acc = h3_tile_from_lds<NT, 7>(unit, in, acc, lane, [&](int c) {
                     if (t > 0 && c < 16) {                     // epilogue of tile t-1, one pair of elements per two chunks
                         if (!(c & 1)) fp = film_pair_load(bias, fr_l, ph_l, t - 1, h, c);
-                        else film_split_pair<STORE>(acc_prev, inv_s, fp, t - 1, h, c - 1, &y[2 * (t - 1)], st);
+                        else film_split_pair<STORE, RESID>(acc_prev, inv_s, fp, t - 1, h, c - 1, &out[2 * (t - 1)], st);
                     }
                 });
                 if (t > 0 && KCH < 16) {                       // narrow networks: the rest of tile t-1's elements
 #pragma unroll
                     for (int r = KCH; r < 16; r += 2)
-                        film_split_pair<STORE>(acc_prev, inv_s, film_pair_load(bias, fr_l, ph_l, t - 1, h, r), t - 1, h, r, &y[2 * (t - 1)], st);
+                        film_split_pair<STORE, RESID>(acc_prev, inv_s, film_pair_load(bias, fr_l, ph_l, t - 1, h, r), t - 1, h, r,
+                                                      &out[2 * (t - 1)], st);
                 }
                 acc_prev = acc;
             }
-            film_split<STORE>(acc_prev, inv_s, bias, fr_l, ph_l, NT - 1, h, &y[2 * (NT - 1)], st);
+            film_split<STORE, RESID>(acc_prev, inv_s, bias, fr_l, ph_l, NT - 1, h, &out[2 * (NT - 1)], st);
             if (STORE) {
                 st.row_h += act_layer;
                 st.row_c += act_layer;
             }
-#pragma unroll
-            for (int c = 0; c < KCH; ++c) x[c] = y[c];
             bias += H;
-            if (film) {
-                lfr += H;
-                lph += H;
+            ++m;
+        };
+        for (int l = 1; l < a.L; ++l) {
+            const int kind = a.layer_kind[l];
+            if (HAS_RES && kind == CNERF_LAYER_RES) {          // y = sin(W1 x + b1);  x = sin(x + W2 y + b2), in place
+                matrix(x, y, ResidNo{}, lds_ones, lds_zeros);
+                matrix(y, x, ResidYes{}, lds_ones, lds_zeros);
+            } else {
+                const bool film = kind == CNERF_LAYER_FILM;
+                matrix(x, y, ResidNo{}, film ? lfr : lds_ones, film ? lph : lds_zeros);
+#pragma unroll
+                for (int c = 0; c < KCH; ++c) x[c] = y[c];
+                if (film) {
+                    lfr += H;
+                    lph += H;
+                }
             }
         }
         BSTAMP(4);
         // ---- head (last unit of the sequence).  Behind its barrier: layer-0 unit 0 streams in for the next group, the
         // next tile's position is finished and its 32 lookups are issued -- they fly under the head's MFMAs.
         {
-            const f16x8* unit = unit_begin(!PAIRED);                  // PAIRED: unit 1 + (L-1) NT of the tile, odd
+            const f16x8* unit = unit_begin(!PAIRED);                  // PAIRED: unit 1 + (n_mats-1) NT of the tile, odd
             float nx, ny, nz;                                   // without a next group: this tile again (harmless, keeps `it` dead above)
             tile_point_finish(a, tn.b, tn.nn, raw_next, tn.valid, h, has_next, nx, ny, nz);
 #ifndef CNERF_H3_NOPREFETCH
@@ -545,7 +573,7 @@ __global__ __launch_bounds__(256) void field_h3_kernel(FieldArgs a) {
             acc = h3_tile_from_lds<NT, 0>(unit, x, acc, lane, [](int) {});
             if (valid && h == 0) {
                 const f32x4 hb = *reinterpret_cast<const f32x4*>(bias);
-                const float inv_s = lds_inv_s[a.L];
+                const float inv_s = lds_inv_s[a.n_mats];
                 f32x4 o;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) o[i] = __builtin_fmaf(acc[i], inv_s, hb[i]);
@@ -578,7 +606,7 @@ static size_t h3_lds_bytes(const FieldArgs& a, int slots) {
     return slots * (size_t)H3Lds<NT>::FRAGS * 16 + ((size_t)a.bias_floats + 2 * NT * 32 + 2 * (size_t)a.film_stride) * 4;
 }
 
-template <int NT, bool STORE, bool PAIRED>
+template <int NT, bool STORE, bool PAIRED, bool HAS_RES>
 static hipError_t launch_h3_inst(const FieldArgs& a, hipStream_t stream) {
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) != hipSuccess) dev = 0;
@@ -587,22 +615,25 @@ static hipError_t launch_h3_inst(const FieldArgs& a, hipStream_t stream) {
     if (lds_bytes > LDS_LIMIT) return hipErrorInvalidValue;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipError_t e = hipFuncSetAttribute((const void*)field_h3_kernel<NT, STORE, PAIRED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT)) return e;
+        if (hipError_t e = hipFuncSetAttribute((const void*)field_h3_kernel<NT, STORE, PAIRED, HAS_RES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT)) return e;
         attr_set = true;
     }
     const long long want = (a.total_tiles / a.tiles_per_image) * ((a.tiles_per_image + 3) / 4), cap = (long long)cus;
     int blocks = (int)(want < cap ? want : cap);
     if (blocks < 8) blocks = 8;
     blocks = (blocks + 7) / 8 * 8;
-    hipLaunchKernelGGL((field_h3_kernel<NT, STORE, PAIRED>), dim3(blocks), dim3(256), lds_bytes, stream, a);
+    hipLaunchKernelGGL((field_h3_kernel<NT, STORE, PAIRED, HAS_RES>), dim3(blocks), dim3(256), lds_bytes, stream, a);
     return hipGetLastError();
 }
 
 template <int NT, bool STORE>
 static hipError_t launch_h3_nt(const FieldArgs& a, hipStream_t stream) {
     // one barrier per two weight units where the unit parity is static (single-input networks) and four slots fit in LDS
-    if (CNERF_H3_SLOTS == 4 && a.n_in == 1 && h3_lds_bytes<NT>(a, 4) <= LDS_LIMIT) return launch_h3_inst<NT, STORE, true>(a, stream);
-    return launch_h3_inst<NT, STORE, false>(a, stream);
+    bool res = false;
+    for (int l = 0; l < a.L; ++l) res |= a.layer_kind[l] == CNERF_LAYER_RES;
+    if (res) return launch_h3_inst<NT, STORE, false, true>(a, stream);
+    if (CNERF_H3_SLOTS == 4 && a.n_in == 1 && h3_lds_bytes<NT>(a, 4) <= LDS_LIMIT) return launch_h3_inst<NT, STORE, true, false>(a, stream);
+    return launch_h3_inst<NT, STORE, false, false>(a, stream);
 }
 
 hipError_t launch_field_h3(const FieldArgs& a, int H, hipStream_t stream) {

@@ -38,11 +38,11 @@ def volumes_struct(levels):
 
 def precision_of(net):
     """Forward arithmetic of `net`: its `.precision` attribute ("fp32" | "fp16x3"), fp16x3 only where the kernel has it
-    (FiLM / plain-sine layers)."""
+    (FiLM / plain-sine / residual layers; the per-point FiLM family runs in fp32)."""
     p = getattr(net, "precision", "fp32")
     if p not in L.PREC_CODE:
         raise L.CnerfError(f"unknown precision {p!r}")
-    if p == "fp16x3" and any(k not in ("film", "sine") for k in net.spec.layers):
+    if p == "fp16x3" and any(k not in ("film", "sine", "res") for k in net.spec.layers):
         return "fp32"
     return p
 

@@ -44,7 +44,8 @@ extern "C" {
 #define CNERF_PREC_FP32 0   /* v_mfma_f32_32x32x2_f32: exact fp32 fmaf chains */
 #define CNERF_PREC_FP16X3 2 /* every fp32 operand split into two fp16 parts (22 significant bits), three fp16 MFMAs per product
                              * with fp32 accumulation, weights pre-scaled per matrix by a power of two: fp32-level accuracy
-                             * (same parity gate) at 3/16 of the fp32 matrix time; forward only, FiLM / sine layers */
+                             * (same parity gate) at 3/16 of the fp32 matrix time; forward and the activation-storing re-run of the
+                             * backward; FiLM / sine / residual layers (not the per-point FiLM family) */
 
 /* layer kinds of the field network (siren.py:146-230) */
 #define CNERF_LAYER_FILM 0 /* y = sin(freq * (W x + b) + phase), freq/phase per image */
