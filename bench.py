@@ -296,11 +296,15 @@ def main():
         roof = {"kernel": "field_tile_kernel<8> (sample + trilinear lookup + FiLM-SIREN MLP, fp32 MFMA)",
                 "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None}
-    # HBM bytes are not measurable from inside this process: `traffic` stays null here; the rocprofv3 PMC passes
-    # (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, profiles/r01_field_kernel_profile.md) give 97 MB per launch at batch 2 for the
-    # fp32 kernel -- the two 33.5 MB channel-last volumes read once, rgb_sigma and z written once -- against 0.86 TFLOP.
+    # HBM bytes cannot be counted from inside this process.  `traffic` is the rocprofv3 PMC measurement of the same kernels on
+    # the same workload shape at batch 2 (scripts/pmc_traffic.sh -> profiles/r01_field_kernel_profile.md: FETCH_SIZE 31,290 KB
+    # x 2 for gfx950's wide reads + WRITE_SIZE 36,860 KB per launch of 2,097,152 points, identical for both field kernels =
+    # 48.5 B per point: the channel-last volumes read once, rgb_sigma and z written once) scaled to this launch's points.
+    PMC_BYTES_PER_POINT = (2 * 31290.0 + 36860.0) * 1024.0 / 2097152.0
+    roof["traffic"] = PMC_BYTES_PER_POINT * B * R * R * S if (R, S, args.volume) == (128, 64, 64) else None
+    roof["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE at batch 2 (profiles/r01_field_kernel_profile.md), scaled by points per launch"
     roof.update({"avg_launch_ms": avg_ms, "launches": len(kern_ms), "flops_per_launch": flops_per_launch,
-                 "traffic_pmc_reference": "profiles/r01_field_kernel_profile.md (97 MB per launch at batch 2, fp32 kernel)",
+
                  "share_of_step": 2 * avg_ms / (elapsed / args.steps * 1e3)})
 
     if rank == 0:
