@@ -216,6 +216,7 @@ def main():
     ap.add_argument("--variant", default="SHORTSIREN_FG")
     ap.add_argument("--hidden", type=int, default=256)
     ap.add_argument("--z-dim", type=int, default=256)
+    ap.add_argument("--input-dim", type=int, default=32, help="generator input_dim (3 for TALLSIREN, whose z_dim is the feature width 32)")
     ap.add_argument("--noise", type=float, default=0.0)
     ap.add_argument("--precision", default="fp32", choices=["fp32", "fp16x3"],
                     help="arithmetic of the MLP products: exact fp32 MFMA, or the fp32-accurate fp16x3 split")
@@ -248,7 +249,7 @@ def main():
     from cnerf_amd.generators import ImplicitGenerator3d
 
     torch.manual_seed(0)                                      # reference default init under seed 0
-    gen_cpu = ImplicitGenerator3d(args.variant, args.z_dim, 32, 4, args.hidden)
+    gen_cpu = ImplicitGenerator3d(args.variant, args.z_dim, args.input_dim, 4, args.hidden)
     import copy
     gen = copy.deepcopy(gen_cpu).to(dev)
     gen.set_device(dev)
