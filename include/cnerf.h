@@ -167,20 +167,6 @@ int cnerf_pack_field(const cnerf_cfg* cfg, const cnerf_field_params* params, flo
 int cnerf_gather_features(const cnerf_cfg* cfg, const float* fvol_cl, const float* points, int64_t n_per_image,
                           float* feat, void* stream);
 
-/* Weight-gradient reduction over a chunk written by cnerf_field_backward:  dW[b] (H,K) += g_arg[b]^T x[b],
- * colsum[b] (H) += sum over points of g_arg[b], per image b < n_images; g_arg (n_images, n_per_image, H) = act_g of one
- * matrix, x (n_images, n_per_image, K) = that matrix' input (act_feat for layer 0, act_h of the previous matrix otherwise),
- * K a multiple of 32.  From these the host forms dW, db, dfreq, dphase (autograd of FiLMLayer / SirenLayer,
- * siren.py:146-199).  Both outputs are accumulated into (zero them first). */
-int cnerf_weight_grad(int32_t n_images, int64_t n_per_image, int32_t H, int32_t K, const float* g_arg, const float* x, float* dW,
-                      float* colsum, void* stream);
-
-/* Adjoint of cnerf_gather_features: grad_fvol_cl (B,V,V,V,32) += scatter of grad_feat (B,n,32) with the trilinear weights of
- * points (B,n,3).  Autograd twin of F.grid_sample (siren.py:555-571) for hosts that evaluate the MLP gradients themselves
- * (the per-point FiLM family, siren.py:232-331). */
-int cnerf_scatter_features(const cnerf_cfg* cfg, const float* points, int64_t n_per_image, const float* grad_feat,
-                           float* grad_fvol_cl, void* stream);
-
 /* Field network at explicit points: points (B,n,3) -> rgb_sigma (B,n,4).
  * Replaces <SIREN>.forward(points, z, img_size, num_steps) (siren.py:637-668 and siblings; extract_shapes.py:63-69).
  * freq/phase: (B, n_film*H) with freq already *15+30 (siren.py:650), NULL when the network has no FiLM layer. */
@@ -245,6 +231,21 @@ int cnerf_field_backward(const cnerf_cfg* cfg, int32_t pass, int32_t image0, int
                          const float* cam2world, const float* u_strat, const float* fine_z,
                          const float* grad_rgb_sigma, const float* saved_rgb_sigma, float* act_feat, float* act_h,
                          float* act_c, float* act_g, float* act_go, const cnerf_grad_volumes* grad_vols, void* stream);
+
+/* Weight-gradient reduction over a chunk written by cnerf_field_backward:  dW[b] (H,K) += g_arg[b]^T x[b],
+ * colsum[b] (H) += sum over points of g_arg[b], per image b < n_images; g_arg (n_images, n_per_image, H) = act_g of one
+ * matrix, x (n_images, n_per_image, K) = that matrix' input (act_feat for layer 0, act_h of the previous matrix otherwise),
+ * K a multiple of 32.  From these the host forms dW, db, dfreq, dphase (autograd of FiLMLayer / SirenLayer,
+ * siren.py:146-199).  Both outputs are accumulated into (zero them first). */
+int cnerf_weight_grad(int32_t n_images, int64_t n_per_image, int32_t H, int32_t K, const float* g_arg, const float* x, float* dW,
+                      float* colsum, void* stream);
+
+/* Adjoint of cnerf_gather_features: grad_fvol_cl (B,V,V,V,32) += scatter of grad_feat (B,n,32) with the trilinear weights of
+ * points (B,n,3).  Autograd twin of F.grid_sample (siren.py:555-571) for hosts that evaluate the MLP gradients themselves
+ * (the per-point FiLM family, siren.py:232-331). */
+int cnerf_scatter_features(const cnerf_cfg* cfg, const float* points, int64_t n_per_image, const float* grad_feat,
+                           float* grad_fvol_cl, void* stream);
+
 
 #ifdef __cplusplus
 }
