@@ -474,6 +474,51 @@ def test_weight_grad_kernel(dev, shape):
     assert ((cs.double() - rcs).abs().max() / rcs.abs().max()).item() < 5e-6
 
 
+def test_precisions_agree_on_random_shapes(dev):
+    """The two forward kernels against each other on two dozen random (family, width, batch, image size, samples, volume)
+    combinations, full hierarchical render with the fine depths of the fp32 run forced into the fp16x3 run: pixels within
+    2e-4, merge order identical.  Catches indexing slips (tile groups, idle waves, image switches, unit sequence lengths)
+    that a fixed fixture shape can hide."""
+    import cnerf_amd
+    from cnerf_amd.generators import ImplicitGenerator3d
+    from oracle import render_oracle as O
+    rs = np.random.RandomState(7)
+    fams = ["SHORTSIREN_FG", "DOUBLESIREN_FG", "TALLSIREN_FG", "SingleSIREN_dg", "SHORTSIREN_F", "SHORTSIREN_FRes", "TALLSIREN_dRes"]
+    for case in range(24):
+        variant = fams[case % len(fams)]
+        H = int(rs.choice([64, 128, 256]))
+        B, R, S, V = int(rs.randint(1, 4)), int(rs.randint(1, 14)), int(rs.randint(2, 70)), int(rs.randint(2, 20))
+        torch.manual_seed(case)
+        has_glob = O.FIELD_SPECS[variant].has_global
+        gen = ImplicitGenerator3d(variant, 32, 32, 4, H).to(dev)
+        gen.set_device(dev)
+        with torch.no_grad():
+            gen.siren.final_layer.weight[3] *= 20
+        fvol = torch.randn(B, 32, V, V, V, device=dev) * 0.5
+        z = (fvol, torch.randn(B, 32, device=dev)) if has_glob else fvol
+        cam = torch.eye(4, device=dev).unsqueeze(0).repeat(B, 1, 1).contiguous()
+        cam[:, 2, 3] = -1.0
+        cam[:, 0, 3] = torch.linspace(-0.2, 0.2, B, device=dev)
+        rng = {"u_strat": torch.rand(B, R * R, S, device=dev), "u_fine": torch.rand(B, R * R, S, device=dev),
+               "eps_coarse": torch.randn(B, R * R, S, device=dev), "eps_final": torch.randn(B, R * R, 2 * S, device=dev)}
+        outs = {}
+        for prec in ("fp32", "fp16x3"):
+            gen.siren.precision = prec
+            aux = {}
+            r = dict(rng)
+            if prec == "fp16x3":
+                r["fine_z"] = outs["fp32"][2]["fine_z"]
+            with torch.no_grad():
+                px, dp = gen(z, cam, R, 49.13, 0.25, 1.95, S, True, clamp_mode="softplus", nerf_noise=0.2, white_back=True, _rng=r, _aux=aux)
+            outs[prec] = (px, dp, aux)
+        a, b = outs["fp32"], outs["fp16x3"]
+        tag = f"case {case}: {variant} H={H} B={B} R={R} S={S} V={V}"
+        assert torch.equal(a[2]["coarse_z"], b[2]["coarse_z"]), tag
+        assert torch.equal(a[2]["sort_idx"], b[2]["sort_idx"]), tag
+        assert (a[0] - b[0]).abs().max().item() < 2e-4, tag
+        assert (a[1] - b[1]).abs().max().item() < 2e-4, tag
+
+
 def test_scatter_is_the_adjoint_of_gather(dev):
     """cnerf_scatter_features against cnerf_gather_features: <gather(v), g> == <v, scatter(g)> for random v, g, points (incl.
     points outside the volume, which clamp to the border like the lookup does)."""
