@@ -23,16 +23,23 @@ def build_library(force=False, verbose=False, extra_flags=()):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     extra_flags = tuple(extra_flags) + tuple(os.environ.get("CNERF_EXTRA_FLAGS", "").split())
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
-    objs = []
+    objs, jobs = [], []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(CSRC, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            cmd = [hipcc, *FLAGS, *extra_flags, "-c", s, "-o", o]
+            jobs.append([hipcc, *FLAGS, *extra_flags, "-c", s, "-o", o])
+    if jobs:      # the translation units are independent: compile them side by side (a handful of processes)
+        from concurrent.futures import ThreadPoolExecutor
+
+        def run(cmd):
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
+
+        with ThreadPoolExecutor(max_workers=min(len(jobs), max(1, (os.cpu_count() or 2) // 2))) as pool:
+            list(pool.map(run, jobs))
     if force or _stale(LIB, objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
         if verbose:
