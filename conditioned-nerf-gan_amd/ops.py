@@ -130,7 +130,13 @@ def channel_last_levels(vols):
 
 
 def channel_last(fvol):
-    """(B,C,V,V,V) -> (B,V,V,V,C) on the GPU (C a multiple of 32)."""
+    """(B,C,V,V,V) -> (B,V,V,V,C) on the GPU (C a multiple of 32).  A volume that already lives in memory channel-last
+    (torch.channels_last_3d, e.g. an encoder whose last convolution writes that format: SURVEY.md 8f-1) is taken as it is:
+    no transpose kernel, no copy."""
+    if fvol.dim() == 5 and fvol.dtype == torch.float32 and fvol.is_cuda:
+        view = fvol.detach().permute(0, 2, 3, 4, 1)
+        if view.is_contiguous() and fvol.shape[2] == fvol.shape[3] == fvol.shape[4]:
+            return view
     fvol = _f32(fvol)
     B, Cc, V = fvol.shape[0], fvol.shape[1], fvol.shape[-1]
     if fvol.shape[2:] != (V, V, V):

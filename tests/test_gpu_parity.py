@@ -519,6 +519,34 @@ def test_precisions_agree_on_random_shapes(dev):
         assert (a[1] - b[1]).abs().max().item() < 2e-4, tag
 
 
+def test_channels_last_volume_is_taken_without_a_copy(dev):
+    """A feature volume in torch.channels_last_3d memory format renders the same image as its contiguous twin, and the
+    channel-last view handed to the kernels aliases the caller's storage."""
+    import cnerf_amd
+    from cnerf_amd import ops
+    from cnerf_amd.generators import ImplicitGenerator3d
+    torch.manual_seed(5)
+    gen = ImplicitGenerator3d("SHORTSIREN_FG", 32, 32, 4, 64).to(dev)
+    gen.set_device(dev)
+    fvol = torch.randn(2, 32, 9, 9, 9, device=dev)
+    fcl = fvol.to(memory_format=torch.channels_last_3d)
+    assert ops.channel_last(fcl).data_ptr() == fcl.data_ptr()
+    glob = torch.randn(2, 32, device=dev)
+    cam = torch.eye(4, device=dev).unsqueeze(0).repeat(2, 1, 1).contiguous()
+    cam[:, 2, 3] = -1.0
+    rng = {"u_strat": torch.rand(2, 36, 8, device=dev), "u_fine": torch.rand(2, 36, 8, device=dev)}
+    with torch.no_grad():
+        a = gen((fvol, glob), cam, 6, 49.13, 0.25, 1.95, 8, True, clamp_mode="relu", nerf_noise=0.0, _rng=rng)
+        b = gen((fcl, glob), cam, 6, 49.13, 0.25, 1.95, 8, True, clamp_mode="relu", nerf_noise=0.0, _rng=rng)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    # and gradients flow back to a channels_last leaf
+    leaf = fcl.clone().requires_grad_(True)
+    gen.train()
+    px, dp = gen((leaf, glob), cam, 6, 49.13, 0.25, 1.95, 8, True, clamp_mode="relu", nerf_noise=0.0, _rng=rng)
+    (px.square().mean() + dp.mean()).backward()
+    assert leaf.grad is not None and torch.isfinite(leaf.grad).all() and leaf.grad.abs().sum() > 0
+
+
 def test_scatter_is_the_adjoint_of_gather(dev):
     """cnerf_scatter_features against cnerf_gather_features: <gather(v), g> == <v, scatter(g)> for random v, g, points (incl.
     points outside the volume, which clamp to the border like the lookup does)."""
