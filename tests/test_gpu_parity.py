@@ -547,6 +547,25 @@ def test_channels_last_volume_is_taken_without_a_copy(dev):
     assert leaf.grad is not None and torch.isfinite(leaf.grad).all() and leaf.grad.abs().sum() > 0
 
 
+def test_extract_shapes_grid(dev):
+    """Density grid helper (second consumer of the siren sub-API, extract_shapes.py:41-78): chunked evaluation equals one
+    direct field call, the sample lattice spans the cube."""
+    import cnerf_amd
+    from cnerf_amd import extract_shapes as X
+    from cnerf_amd.generators import ImplicitGenerator3d
+    torch.manual_seed(11)
+    gen = ImplicitGenerator3d("SHORTSIREN_FG", 32, 32, 4, 64).to(dev)
+    gen.set_device(dev)
+    z = (torch.randn(1, 32, 8, 8, 8, device=dev), torch.randn(1, 32, device=dev))
+    N = 12
+    pts, corner, pitch = X.create_samples(N, cube_length=1.2)
+    assert pts.shape == (1, N ** 3, 3) and abs(float(pts.min()) + 0.6) < 1e-6 and abs(float(pts[..., 2].max()) - 0.6) < 1e-5
+    grid = X.sample_generator(gen, z, voxel_resolution=N, max_points=500)        # ragged chunks on purpose
+    with torch.no_grad():
+        direct = gen.siren(pts.to(dev), z, N, 1)[..., 3].reshape(N, N, N).cpu().numpy()
+    assert grid.shape == (N, N, N) and np.array_equal(grid, direct)
+
+
 def test_scatter_is_the_adjoint_of_gather(dev):
     """cnerf_scatter_features against cnerf_gather_features: <gather(v), g> == <v, scatter(g)> for random v, g, points (incl.
     points outside the volume, which clamp to the border like the lookup does)."""
