@@ -60,3 +60,52 @@ def test_discriminator_resolutions_and_fade(res):
     # state-dict names the reference's checkpoints use
     keys = d.state_dict().keys()
     assert "layers.0.network.0.conv.weight" in keys and "fromRGB.8.model.0.bias" in keys and "final_layer.weight" in keys
+
+
+def test_on_disk_formats_round_trip(tmp_path):
+    """voxel.npz / cameras.npz readers (datasets.py:104-148) and the checkpoint dictionary (utils.py:463-501, key names of the
+    reference) on synthetic files: layout conventions and a save / load round trip through weights_only loading."""
+    import types
+    from cnerf_amd.training import load_voxel_npz, load_cam2world, save_checkpoint, load_checkpoint, UNet3D, ProgressiveDiscriminator
+    from cnerf_amd.generators import ImplicitGenerator3d
+    rs = np.random.RandomState(0)
+    vox = rs.rand(8, 8, 8, 4).astype(np.float32)                     # (X, Y, Z, [occ, r, g, b])
+    np.savez(tmp_path / "voxel.npz", voxel=vox)
+    t = load_voxel_npz(tmp_path / "voxel.npz", resolution=8)
+    assert t.shape == (4, 8, 8, 8) and t.dtype == torch.float32
+    assert float(t[1, 2, 3, 5]) == float(vox[5, 3, 2, 1])           # (c, z, y, x) <- (x, y, z, c)
+    with pytest.raises(ValueError):
+        load_voxel_npz(tmp_path / "voxel.npz", resolution=64)
+    mats = {f"world_mat_inv_{i}": rs.rand(4, 4) for i in range(3)}
+    np.savez(tmp_path / "cameras.npz", **mats)
+    m = load_cam2world(tmp_path / "cameras.npz", 2)
+    assert m.dtype == torch.float32 and np.allclose(m.numpy(), mats["world_mat_inv_2"].astype(np.float32))
+
+    def make():
+        torch.manual_seed(0)
+        tr = types.SimpleNamespace()
+        tr.device = torch.device("cpu")
+        tr.metadata = {"enable_discriminator": True}
+        tr.generator = ImplicitGenerator3d("SHORTSIREN_FG", 16, 32, 4, 64)
+        tr.encoder = UNet3D(in_channels=4, out_channels=32, f_maps=8, num_levels=2, return_global=True)
+        tr.discriminator = ProgressiveDiscriminator()
+        for name, mod in (("G", tr.generator), ("E", tr.encoder), ("D", tr.discriminator)):
+            setattr(tr, "optimizer_" + name, torch.optim.Adam(mod.parameters(), lr=1e-3, betas=(0.0, 0.9)))
+        tr.losses = {"g": [0.5], "d": [1.25], "photo": [0.1]}
+        return tr
+
+    a = make()
+    a.generator.step = 41
+    with torch.no_grad():
+        a.generator.siren.final_layer.bias += 1.0
+    path = save_checkpoint(a, tmp_path / "checkpoints")
+    assert path.endswith("41.tar")
+    raw = torch.load(path, weights_only=True)
+    for k in ("step", "generator_state_dict", "optimizer_G_state_dict", "encoder_state_dict", "optimizer_E_state_dict",
+              "discriminator_state_dict", "optimizer_D_state_dict"):
+        assert k in raw
+    assert "siren.network.0.layer.weight" in raw["generator_state_dict"]
+    b = make()
+    load_checkpoint(b, path)
+    assert b.generator.step == 41
+    assert torch.equal(b.generator.siren.final_layer.bias, a.generator.siren.final_layer.bias)
