@@ -33,6 +33,8 @@ def main():
     ap.add_argument("--precision", default="fp32", choices=["fp32", "fp16x3"], help="arithmetic of the forward render")
     ap.add_argument("--no-miopen-find", action="store_true",
                     help="keep MIOpen's immediate-mode kernel choice for the Conv3d/Conv2d layers (fast start, 3x slower steps)")
+    ap.add_argument("--checkpoint-dir", default=None, help="write <step>.tar (the reference's checkpoint keys) after the last step")
+    ap.add_argument("--resume", default=None, help="a <step>.tar written by this harness or by the reference's trainer")
     ap.add_argument("-p", "--print-freq", type=int, default=1)
     args = ap.parse_args()
 
@@ -59,6 +61,11 @@ def main():
     md["miopen_find"] = not args.no_miopen_find
     md["encoder_channels_last"] = bool(int(os.environ.get("CNERF_ENCODER_CHANNELS_LAST", "0")))
     trainer = GanTrainer(md, dev, ddp=world > 1)
+    if args.resume:
+        from cnerf_amd.training import load_checkpoint
+        ck = load_checkpoint(trainer, args.resume)
+        if rank == 0:
+            print(f"resumed from {args.resume} at step {ck['step']}", flush=True)
     gen = torch.Generator().manual_seed(1000 + rank)
     import threading
     first_done = threading.Event()
@@ -82,6 +89,11 @@ def main():
             print(f"step {step}: D {trainer.losses['d'][-1]:.4f}  G {trainer.losses['g'][-1]:.4f}  photo {trainer.losses['photo'][-1]:.4f}  "
                   f"alpha {trainer.alpha:.3f}  nerf_noise {md['nerf_noise']:.3f}  sec/step {dt:.3f}  "
                   f"({world * args.batch * args.img_size ** 2 * 2 / dt / 1e6:.2f} M rays/s rendered, D + G passes)", flush=True)
+    if args.checkpoint_dir and rank == 0:
+        from cnerf_amd.training import save_checkpoint
+        trainer.generator.step -= 1                       # the step that was just completed, as the reference names its files
+        print("saved", save_checkpoint(trainer, args.checkpoint_dir), flush=True)
+        trainer.generator.step += 1
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
