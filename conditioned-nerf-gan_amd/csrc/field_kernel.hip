@@ -246,6 +246,9 @@ __device__ __forceinline__ void film_all(const f32x16* y, f32x16* x, const float
 // from layer 0 but the 32 scattered global_load_lds instructions cost 8.6 k cycles to issue in the head (~200 cycles each:
 // M0 rewrite + 32 distinct lines per instruction), a net loss of 0.5 %; only the one-tile-ahead fetch of the raw sample
 // coordinate is kept by default.
+#ifndef CNERF_F32_HEAD_LDS
+#define CNERF_F32_HEAD_LDS 1
+#endif
 #ifndef CNERF_F32_LOOKUP_DMA
 #define CNERF_F32_LOOKUP_DMA 0
 #endif
@@ -266,6 +269,17 @@ __global__ __launch_bounds__(256) void field_tile_kernel(FieldArgs a) {
     constexpr bool PF = CNERF_F32_LOOKUP_DMA && NT >= 4;
     extern __shared__ __attribute__((aligned(16))) char smem_q[];
     f32x4* lds_wave = reinterpret_cast<f32x4*>(smem_q) + (threadIdx.x >> 6) * (32 * 64);     // 32 KiB per wave
+
+    // The head's weights (4x4x1 MFMA layout: NT*4 float4 per lane) are read in full by every wave for every tile -- as many
+    // bytes as the lookups.  They are parked in LDS once per block instead of streamed from L2 once per tile.
+#if CNERF_F32_HEAD_LDS
+    __shared__ f32x4 s_head[NT * 4 * 64];
+    {
+        const f32x4* head_w = reinterpret_cast<const f32x4*>(a.packed) + ((size_t)NT * a.n_in + (size_t)(a.n_mats - 1) * NT * NT) * TILE4;
+        for (int i = threadIdx.x; i < NT * 4 * 64; i += 256) s_head[i] = head_w[i];
+        __syncthreads();
+    }
+#endif
 
     const TileRange tr = tile_range(a.total_tiles);
     auto point_of = [&](long long tile, int& b_, long long& nn_, bool& valid_) {
@@ -385,7 +399,11 @@ __global__ __launch_bounds__(256) void field_tile_kernel(FieldArgs a) {
 
         // ---- head: 4 outputs on the 4x4x1 MFMA (16 blocks of 4 points), see pack_head_kernel -------------------------------
         {
+#if CNERF_F32_HEAD_LDS
+            const f32x4 acc = head_forward<NT>(s_head, bias, x.v, lane);
+#else
             const f32x4 acc = head_forward<NT>(wp, bias, x.v, lane);
+#endif
             if (valid && h == 0) {
                 f32x4 o;
                 if (a.flags & CNERF_F_SIGMOID_RGB) {
