@@ -209,10 +209,18 @@ __device__ __forceinline__ void layer0_accumulate(const f32x4* __restrict__ wp, 
 template <int NT, bool STORE>
 __device__ __forceinline__ void film_all(const f32x16* y, f32x16* x, const float* __restrict__ freq,
                                          const float* __restrict__ phase, int h, float* row_h, float* row_c) {
+    f32x16 fr_n = load_chan16(freq, 0, h), ph_n = load_chan16(phase, 0, h);      // per-channel vectors one tile ahead of their use
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        const f32x16 fr = load_chan16(freq, t, h);
-        const f32x16 ph = load_chan16(phase, t, h);
+#if CNERF_F32_FILM_PREFETCH
+        const f32x16 fr = fr_n, ph = ph_n;
+        if (t + 1 < NT) {
+            fr_n = load_chan16(freq, t + 1, h);
+            ph_n = load_chan16(phase, t + 1, h);
+        }
+#else
+        const f32x16 fr = t == 0 ? fr_n : load_chan16(freq, t, h), ph = t == 0 ? ph_n : load_chan16(phase, t, h);
+#endif
         f32x16 o, cs;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -225,6 +233,7 @@ __device__ __forceinline__ void film_all(const f32x16* y, f32x16* x, const float
             store_tile_rows(row_h, t, h, o);
             store_tile_rows(row_c, t, h, cs);
         }
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -246,6 +255,9 @@ __device__ __forceinline__ void film_all(const f32x16* y, f32x16* x, const float
 // from layer 0 but the 32 scattered global_load_lds instructions cost 8.6 k cycles to issue in the head (~200 cycles each:
 // M0 rewrite + 32 distinct lines per instruction), a net loss of 0.5 %; only the one-tile-ahead fetch of the raw sample
 // coordinate is kept by default.
+#ifndef CNERF_F32_FILM_PREFETCH
+#define CNERF_F32_FILM_PREFETCH 1
+#endif
 #ifndef CNERF_F32_HEAD_LDS
 #define CNERF_F32_HEAD_LDS 1
 #endif
