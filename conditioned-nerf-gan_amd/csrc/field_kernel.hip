@@ -120,41 +120,21 @@ __device__ __forceinline__ void store_tile_rows(float* __restrict__ row /* &buf[
 // scripts/ubench/mfma_valu_overlap.hip): VALU instructions do NOT hide under v_mfma_f32_32x32x2_f32 -- each adds its
 // full 2 cycles whether spread between the MFMAs or clumped, with one or two accumulator chains -- so for the fp32
 // path  time = MFMA + VALU + stalls  and the epilogue placement only matters for register pressure and load distance.
-// What a matrix needs before its first MFMA: the first RING weight groups and the bias of output tile 0.  Fetched by the
-// PREVIOUS matrix just before its last (un-pipelined) epilogue -- weights and biases of consecutive matrices are
-// contiguous in the packed stream -- so that the L2 round trip hides under that epilogue instead of opening the layer.
-struct MatrixPrefetch {
-    f32x4 ring[RING];
-    f32x16 bias0;
-};
-__device__ __forceinline__ void matrix_prefetch(MatrixPrefetch& pf, const f32x4* __restrict__ wp, const float* __restrict__ bias, int lane, int h) {
-#pragma unroll
-    for (int i = 0; i < RING; ++i) pf.ring[i] = wp[i * 64 + lane];
-    pf.bias0 = load_chan16(bias, 0, h);
-}
-
 template <int OT, int KT, int EPI, bool STORE>
 __device__ __forceinline__ void mlp_matrix(const f32x4* __restrict__ wp, const float* __restrict__ bias,
                                            const float* __restrict__ freq, const float* __restrict__ phase,
                                            const f32x16* in, const f32x16* res, f32x16* out, int lane, int h,
-                                           float* __restrict__ row_h, float* __restrict__ row_c, MatrixPrefetch* pf = nullptr) {
+                                           float* __restrict__ row_h, float* __restrict__ row_c) {
     constexpr int GPT = KT * 4;                       // groups (of 4 MFMAs) per output tile
     constexpr int NG = OT * GPT;
     constexpr int EPG = GPT >= 16 ? 1 : 16 / GPT;     // epilogue elements handled per group
     constexpr int ESTEP = GPT >= 16 ? GPT / 16 : 1;   // ... every ESTEP-th group
-    static_assert(NG >= RING, "matrix shorter than the prefetch ring");
     f32x4 ring[RING];
-    f32x16 bias_next;                                 // per-channel vectors are fetched one output tile ahead
-    if (pf) {
 #pragma unroll
-        for (int i = 0; i < RING; ++i) ring[i] = pf->ring[i];
-        bias_next = pf->bias0;
-    } else {
-#pragma unroll
-        for (int i = 0; i < RING; ++i) ring[i] = wp[i * 64 + lane];
-        bias_next = load_chan16(bias, 0, h);
-    }
+    for (int i = 0; i < RING; ++i)
+        if (i < NG) ring[i] = wp[i * 64 + lane];
     f32x16 acc_prev, fr_prev, ph_prev, cos_t;
+    f32x16 bias_next = load_chan16(bias, 0, h);       // per-channel vectors are fetched one output tile ahead
 #pragma unroll
     for (int t = 0; t < OT; ++t) {
         f32x16 acc = bias_next;
@@ -189,10 +169,6 @@ __device__ __forceinline__ void mlp_matrix(const f32x4* __restrict__ wp, const f
         acc_prev = acc;
         fr_prev = fr;
         ph_prev = ph;
-    }
-    if (pf) {                                         // the next matrix follows this one in the packed stream
-        matrix_prefetch(*pf, wp + (size_t)NG * 64, bias + OT * 32, lane, h);
-        __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -279,9 +255,6 @@ __device__ __forceinline__ void film_all(const f32x16* y, f32x16* x, const float
 // from layer 0 but the 32 scattered global_load_lds instructions cost 8.6 k cycles to issue in the head (~200 cycles each:
 // M0 rewrite + 32 distinct lines per instruction), a net loss of 0.5 %; only the one-tile-ahead fetch of the raw sample
 // coordinate is kept by default.
-#ifndef CNERF_F32_MATRIX_PREFETCH
-#define CNERF_F32_MATRIX_PREFETCH 1
-#endif
 #ifndef CNERF_F32_FILM_PREFETCH
 #define CNERF_F32_FILM_PREFETCH 1
 #endif
@@ -376,9 +349,6 @@ __global__ __launch_bounds__(256) void field_tile_kernel(FieldArgs a) {
             layer0_accumulate<NT>(wp, a.n_in, tk, feat, y.v, lane);
         }
         STAMP(1);   // position + lookups + layer-0 products
-        MatrixPrefetch pf;      // first weights / bias of the next matrix, in flight under the epilogue in front of it
-        MatrixPrefetch* pfp = CNERF_F32_MATRIX_PREFETCH ? &pf : nullptr;
-        if (pfp && a.L > 1) matrix_prefetch(pf, wp + (size_t)NT * a.n_in * TILE4, bias + H, lane, h);
         {
             const bool film = a.layer_kind[0] == CNERF_LAYER_FILM;
             film_all<NT, STORE>(y.v, x.v, film ? freq : ones, film ? phase : zeros, h, row_h, row_c);
@@ -400,7 +370,7 @@ __global__ __launch_bounds__(256) void field_tile_kernel(FieldArgs a) {
             if (!HAS_RES || kind != CNERF_LAYER_RES) {
                 const bool film = kind == CNERF_LAYER_FILM;
                 mlp_matrix<NT, NT, EPI_FILM, STORE>(wp, bias, film ? freq : ones, film ? phase : zeros, x.v, nullptr, y.v, lane,
-                                                    h, row_h, row_c, pfp);
+                                                    h, row_h, row_c);
                 if (STORE) {
                     row_h += act_layer;
                     row_c += act_layer;
@@ -417,14 +387,14 @@ __global__ __launch_bounds__(256) void field_tile_kernel(FieldArgs a) {
                 STAMP(3);   // hidden layers
             } else {
                 // y = sin(W1 x + b1);  x = sin(x + W2 y + b2)   (tile t of x is dead once its own residual is added)
-                mlp_matrix<NT, NT, EPI_FILM, STORE>(wp, bias, ones, zeros, x.v, nullptr, y.v, lane, h, row_h, row_c, pfp);
+                mlp_matrix<NT, NT, EPI_FILM, STORE>(wp, bias, ones, zeros, x.v, nullptr, y.v, lane, h, row_h, row_c);
                 if (STORE) {
                     row_h += act_layer;
                     row_c += act_layer;
                 }
                 wp += (size_t)NT * NT * TILE4;
                 bias += H;
-                mlp_matrix<NT, NT, EPI_FILM_RES, STORE>(wp, bias, ones, zeros, y.v, x.v, x.v, lane, h, row_h, row_c, pfp);
+                mlp_matrix<NT, NT, EPI_FILM_RES, STORE>(wp, bias, ones, zeros, y.v, x.v, x.v, lane, h, row_h, row_c);
                 if (STORE) {
                     row_h += act_layer;
                     row_c += act_layer;
