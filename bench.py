@@ -2,17 +2,25 @@
 """Headline benchmark of the render path: rays/s of ImplicitGenerator3d.forward at 128x128x64 spp on synthetic
 ShapeNetCar-shaped inputs (BASELINE.json metric).
 
-  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1 runs one rank per GPU: either the driver starts the ranks itself (`python -m torch.distributed.run ... bench.py
+--gpus N`, WORLD_SIZE in the environment) or this process does -- with WORLD_SIZE unset it only launches N children
+through torch.distributed.run BEFORE anything touches the GPU, relays rank 0's JSON line and returns their exit code.
 
 A step = one generator forward over this rank's B images (the four random draws, FiLM mapping, channel-last copy of the
 feature volume, weight packing, coarse pass, resampling, fine pass, merge + composite).  Inputs are resident in HBM
 before the timed region.  Rank 0 prints ONE JSON line with the whole-job rays/s, the roofline of the dominant kernel
-(timed with HIP events recorded inside the timed region) and, at N=1, the CPU oracle timed on a bounded sample.
+(timed with HIP events recorded inside the timed region) and, at N=1, the CPU oracle timed on image 0 of the SAME inputs
+and draws -- whose output is also the checker of the timed run (`check`): the run fails if the image the GPU produced in
+its last timed step does not match it.
 """
 import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,7 +32,10 @@ import torch
 
 FOV, RAY_START, RAY_END = 49.134342641202636, 0.25, 1.95     # configs/thousand/special.py:35-41 of the reference
 PEAK_F32_MFMA_TFLOPS = 157.3                                  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_F16_MFMA_TFLOPS = 2500.0
 PEAK_HBM_GBPS = 8000.0
+CHECK_SEED = 4242                                             # torch.cuda seed of the draws of the last timed step
+PMC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE per kernel (scripts/pmc_traffic.sh)
 
 
 def macs_per_point(C, H, n_layers):
@@ -49,6 +60,9 @@ class HipEvents:
             assert self.hip.hipEventCreate(ctypes.byref(e)) == 0
             out.append(e.value)
         return out
+
+    def record(self, ev):
+        self.hip.hipEventRecord(ev, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
 
     def elapsed_ms(self, a, b):
         ms = ctypes.c_float()
@@ -98,10 +112,70 @@ def synthetic_inputs(B, V, Z, dev, seed):
     return fvol.to(dev), glob.to(dev), cam.to(dev)
 
 
+def zin(gen, fvol, glob):
+    """The generator's `z`: (feature volume, global feature) for the globally conditioned families, the volume alone otherwise."""
+    return (fvol, glob) if gen.siren.spec.has_global else fvol
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# N > 1 without a launcher: start the ranks as children (never exec, never after the GPU is initialised)
+# ---------------------------------------------------------------------------------------------------------------------
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_children(n, argv):
+    """Runs `python -m torch.distributed.run --nproc-per-node n bench.py <argv>` as a child process, forwards its output
+    (rank 0's JSON line on stdout) and returns its exit code.  This process has not touched the GPU."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__), *argv]
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    lines = []
+    for line in proc.stdout:
+        lines.append(line)
+    rc = proc.wait()
+    json_lines = [l for l in lines if l.lstrip().startswith("{") and '"metric"' in l]
+    for l in lines:
+        if l not in json_lines:
+            sys.stderr.write(l)
+    if json_lines:
+        sys.stdout.write(json_lines[-1])
+        sys.stdout.flush()
+    elif rc == 0:
+        sys.stderr.write("bench.py: the ranks printed no result line\n")
+        rc = 1
+    return rc
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# secondary measurements (N = 1)
+# ---------------------------------------------------------------------------------------------------------------------
+def pmc_bytes(kernel_prefix):
+    """HBM bytes per unit of work of one kernel from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json, written
+    by scripts/pmc_traffic.py from separate --pmc FETCH_SIZE / WRITE_SIZE runs; FETCH_SIZE doubled as the guide prescribes
+    for gfx950's wide reads).  None when the file or the kernel is missing."""
+    try:
+        with open(PMC_FILE) as f:
+            tab = json.load(f)
+    except (OSError, ValueError):
+        return None
+    for k, v in tab.get("kernels", {}).items():
+        if k.startswith(kernel_prefix):
+            return v
+    return None
+
+
 def sample_composite_pass(args, gen, fvol, glob, cam, meta, evs):
     """The unfused sample + composite pass of SURVEY.md 8(d): trilinear lookup that materialises the (N,32) features
     (cnerf_gather_features) for every coarse and fine sample of one step, plus the compositing of the merged samples
-    (cnerf_composite).  Algorithmic bytes: 1152 B per field evaluation, 20 B per composited sample, 16 B per ray."""
+    (cnerf_composite).  Two rates are reported: `frac` = HBM bytes measured by rocprofv3 PMC counters / time / 8 TB/s (the
+    roofline fraction), and `l2_side` = the algorithmic bytes of SURVEY 8(d) (1152 B per field evaluation, 20 B per
+    composited sample, 16 B per ray -- mostly corner lines served by L2 / Infinity Cache) / time."""
     import cnerf_amd
     ops = cnerf_amd.ops
     B, R, S = args.batch, args.img_size, args.num_steps
@@ -120,29 +194,36 @@ def sample_composite_pass(args, gen, fvol, glob, cam, meta, evs):
         ev = evs.create(4)
         for i in range(reps + 2):
             if i == 2:
-                evs.hip.hipEventRecord(ev[0], ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+                evs.record(ev[0])
             ops.gather_features(gen.siren, fcl, pts)
-        evs.hip.hipEventRecord(ev[1], ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        evs.record(ev[1])
         for i in range(reps + 2):
             if i == 2:
-                evs.hip.hipEventRecord(ev[2], ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+                evs.record(ev[2])
             ops.composite(rss, zs, None, 0.0, "relu", True, False)
-        evs.hip.hipEventRecord(ev[3], ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        evs.record(ev[3])
         torch.cuda.synchronize()
     t_g = evs.elapsed_ms(ev[0], ev[1]) / reps
     t_c = evs.elapsed_ms(ev[2], ev[3]) / reps
     evals, rays = pts.shape[0] * pts.shape[1], B * R * R
     bytes_g, bytes_c = evals * 1152.0, evals * 20.0 + rays * 16.0
-    gbps = (bytes_g + bytes_c) / ((t_g + t_c) * 1e-3) / 1e9
-    return {"kernels": "gather_kernel (cnerf_gather_features) + composite_kernel (cnerf_composite), unfused",
-            "bound": "hbm", "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS,
-            "traffic": None, "gather_ms": t_g, "composite_ms": t_c, "algorithmic_bytes": bytes_g + bytes_c,
-            "note": "effective bandwidth: neighbouring samples share corner lines in L2 / Infinity Cache (SURVEY.md 8d)"}
-
-
-def zin(gen, fvol, glob):
-    """The generator's `z`: (feature volume, global feature) for the globally conditioned families, the volume alone otherwise."""
-    return (fvol, glob) if gen.siren.spec.has_global else fvol
+    l2_gbps = (bytes_g + bytes_c) / ((t_g + t_c) * 1e-3) / 1e9
+    out = {"kernels": "gather_kernel (cnerf_gather_features) + composite_kernel (cnerf_composite), unfused",
+           "bound": "hbm", "peak": PEAK_HBM_GBPS, "unit": "GB/s", "gather_ms": t_g, "composite_ms": t_c,
+           "algorithmic_bytes": bytes_g + bytes_c,
+           "l2_side": {"achieved": l2_gbps, "peak": 34500.0, "unit": "GB/s", "frac": l2_gbps / 34500.0,
+                       "note": "algorithmic bytes / time: neighbouring samples share corner lines, so most of them are "
+                               "served by the XCD L2s (34.5 TB/s aggregate) and the Infinity Cache, not by HBM"}}
+    pg, pc = pmc_bytes("cnerf::gather_kernel"), pmc_bytes("cnerf::composite_kernel")
+    if pg and pc and (R, S, args.volume) == (128, 64, 64):
+        traffic = pg["bytes_per_point"] * evals + pc["bytes_per_point"] * evals
+        out.update({"traffic": traffic, "achieved": traffic / ((t_g + t_c) * 1e-3) / 1e9,
+                    "traffic_source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes ({os.path.relpath(PMC_FILE, ROOT)}), per point x points"})
+        out["frac"] = out["achieved"] / PEAK_HBM_GBPS
+    else:
+        out.update({"traffic": None, "achieved": None, "frac": None,
+                    "traffic_source": "no PMC measurement for this shape: HBM fraction not reported"})
+    return out
 
 
 def fast_path(args, gen, fvol, glob, cam, meta, evs):
@@ -171,37 +252,153 @@ def fast_path(args, gen, fvol, glob, cam, meta, evs):
     return {"value": B * R * R / dt, "unit": "rays/s", "ms_per_step": dt * 1e3, "dtype": "fp16x3 (fp32-equivalent split, fp32 accumulate)",
             "kernel": "field_h3_kernel<8>", "avg_launch_ms": ms,
             "algorithmic_tflops": flops / (ms * 1e-3) / 1e12,
-            "fp16_mfma_tflops": 3 * flops / (ms * 1e-3) / 1e12, "fp16_mfma_peak": 2500.0,
-            "frac_of_fp16_mfma_peak": 3 * flops / (ms * 1e-3) / 1e12 / 2500.0}
+            "fp16_mfma_tflops": 3 * flops / (ms * 1e-3) / 1e12, "fp16_mfma_peak": PEAK_F16_MFMA_TFLOPS,
+            "frac_of_fp16_mfma_peak": 3 * flops / (ms * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS}
 
 
-def cpu_baseline(args, gen_cpu):
-    """The CPU oracle (same ATen op sequence as the reference's CPU path) on one image of the same workload."""
+def train_step_timing(args, gen, fvol, glob, cam, evs):
+    """Secondary measurement: forward + backward of the render path (what the generator step of the GAN loop adds to the
+    forward), nerf_noise 1.0 as at training step 0, gradients w.r.t. field parameters, FiLM mapping, feature volume and
+    global feature.  Priced against 3x the forward's algorithmic FLOPs (forward + two gradient GEMMs per layer)."""
+    B, R, S = args.batch, args.img_size, args.num_steps
+    meta = dict(clamp_mode="relu", nerf_noise=1.0, white_back=True, hierarchical_sample=True)
+    gen.train()
+    fv = fvol.detach().clone().requires_grad_(True)
+    gl = glob.detach().clone().requires_grad_(True)
+    reps = 3
+    torch.cuda.reset_peak_memory_stats()
+    times = []
+    try:
+        for i in range(reps + 1):
+            for p in gen.parameters():
+                p.grad = None
+            fv.grad = gl.grad = None
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            px, dp = gen(zin(gen, fv, gl), cam, R, FOV, RAY_START, RAY_END, S, **meta)
+            (px.square().mean() + dp.mean()).backward()
+            torch.cuda.synchronize()
+            if i > 0:
+                times.append(time.perf_counter() - t0)
+    finally:
+        gen.eval()
+    dt = float(np.median(times))
+    flops = 3 * 2 * 2.0 * macs_per_point(32, args.hidden, len(gen.siren.spec.layers)) * B * R * R * S
+    return {"fwd_bwd_ms": dt * 1e3, "precision": gen.siren.precision, "images": B,
+            "achieved_tflops_over_3x_forward_flops": flops / dt / 1e12, "peak_mem_gib": torch.cuda.max_memory_allocated() / 2 ** 30,
+            "rays_per_s_fwd_bwd": B * R * R / dt}
+
+
+def host_cores():
+    return len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+
+
+def cpu_baseline(args, gen_cpu, fvol, glob, cam, draws):
+    """The CPU oracle (same ATen op sequence as the reference's CPU path) on image 0 of the bench's own inputs and draws.
+    Returns (baseline dict, oracle output of that image): the output is the checker of the timed GPU run."""
     from oracle import render_oracle as O
     R, S = args.img_size, args.num_steps
-    g = torch.Generator().manual_seed(1234)
-    fvol = torch.randn(1, 32, args.volume, args.volume, args.volume, generator=g)
-    glob = torch.randn(1, args.z_dim, generator=g)
-    cam = torch.eye(4).unsqueeze(0).clone()
-    cam[0, 2, 3] = -1.0
     params = {k: v.detach() for k, v in gen_cpu.siren.state_dict().items()}
-    # a 1-GPU box grants a 16-core share of the host (more threads than that only oversubscribe it)
-    cores = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16)
+    cores = host_cores()                       # the affinity mask the box grants this process (16 for a 1-GPU share)
     torch.set_num_threads(cores)
-    times = []
+    f0, c0 = fvol[:1].cpu(), cam[:1].cpu()
+    g0 = glob[:1].cpu() if gen_cpu.siren.spec.has_global else None
+    B = fvol.shape[0]
+    d0 = {k: v.reshape(B, R * R, -1)[:1].cpu() for k, v in draws.items()}       # image 0 of every draw, (1, P, S or 2S)
+    times, ref = [], None
     with torch.no_grad():
         for i in range(1 + args.cpu_reps):
-            u1, u2 = torch.rand(1, R * R, S, generator=g), torch.rand(1, R * R, S, generator=g)
             t0 = time.perf_counter()
-            O.render(args.variant, params, fvol, glob, cam, R, FOV, RAY_START, RAY_END, S, True, "relu", 0.0, True, False,
-                     u1, None, u2, None)
+            out = O.render(args.variant, params, f0, g0, c0, R, FOV, RAY_START, RAY_END, S, True, "relu", args.noise, True, False,
+                           d0["u_strat"], d0.get("eps_coarse"), d0["u_fine"], d0.get("eps_final"))
             dt = time.perf_counter() - t0
-            if i > 0:
+            if i == 0:
+                ref = out
+            else:
                 times.append(dt)
-    t = float(np.median(times))
-    return {"value": R * R / t, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"1 image {R}x{R}x{S} hierarchical fp32 no_grad, median of {args.cpu_reps} after 1 warm-up "
-                      f"({t:.2f} s each), oracle/render_oracle.py (ATen op sequence of the reference CPU path)"}
+    t = float(np.median(times)) if times else dt
+    return ({"value": R * R / t, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
+             "sample": f"image 0 of the bench's own batch ({R}x{R}x{S} hierarchical fp32 no_grad), median of {max(args.cpu_reps, 1)} after 1 "
+                       f"warm-up ({t:.2f} s each), oracle/render_oracle.py (ATen op sequence of the reference CPU path)"}, ref)
+
+
+def scaled_err(a, b):
+    """max |a-b| / max(|b|, rms(b)) -- the metric of tests/conftest.py."""
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    floor = max(float(np.sqrt(np.mean(b * b))), 1e-30)
+    return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), floor)))
+
+
+def survey_metric_pass(a, b):
+    """Fraction of elements inside the gate SURVEY.md 8(d) wrote down: |a-b| <= 1e-4 * max(|b|, 1e-3)."""
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.mean(np.abs(a - b) <= 1e-4 * np.maximum(np.abs(b), 1e-3)))
+
+
+def check_against_oracle(args, gen, fvol, glob, cam, meta, draws, ref, timed_pixels, timed_depth):
+    """Ties the timed run to a checked image.  (i) the last timed step drew its random tensors from CHECK_SEED: re-rendering
+    with those tensors injected must reproduce its output bit for bit; (ii) image 0 of that render against the CPU oracle
+    on identical inputs and draws: sample positions bit-exact, coarse rgb/sigma within 1e-4, resampling bins identical
+    (>= 99 %); (iii) with the oracle's fine depths forced (sample positions identical downstream of the resampling, see
+    DESIGN.md 4): fine rgb/sigma, pixels and depth within the gate, merge order identical."""
+    B, R, S = args.batch, args.img_size, args.num_steps
+    z = zin(gen, fvol, glob)
+    aux = {}
+    with torch.no_grad():
+        px, dp = gen(z, cam, R, FOV, RAY_START, RAY_END, S, _rng=draws, _aux=aux, **meta)
+    chk = {"timed_output_reproduced": bool(torch.equal(px, timed_pixels) and torch.equal(dp, timed_depth))}
+    a0 = {k: v[0].cpu().numpy() for k, v in aux.items()}
+    r0 = {k: v[0].numpy() for k, v in ref.aux.items()}
+    chk["points_bit_exact"] = bool(np.array_equal(a0["coarse_points"], r0["coarse_points"]) and np.array_equal(a0["coarse_z"], r0["coarse_z"]))
+    chk["rgb_sigma_err"] = max(scaled_err(a0["coarse_rgb_sigma"][..., :3], r0["coarse_rgb_sigma"][..., :3]),
+                               scaled_err(a0["coarse_rgb_sigma"][..., 3], r0["coarse_rgb_sigma"][..., 3]))
+    chk["rgb_sigma_survey_metric_pass"] = survey_metric_pass(a0["coarse_rgb_sigma"], r0["coarse_rgb_sigma"])
+    chk["inds_equal"] = float(np.mean(a0["inds"] == r0["inds"]))
+    chk["pixels_mean_abs_err_free_running"] = float(np.abs(px[0].cpu().numpy() - ref.pixels[0].numpy()).mean())
+    forced = dict(draws)
+    fz = aux["fine_z"].clone()
+    fz[0] = ref.aux["fine_z"][0].to(fz.device)
+    forced["fine_z"] = fz
+    aux2 = {}
+    with torch.no_grad():
+        px2, dp2 = gen(z, cam, R, FOV, RAY_START, RAY_END, S, _rng=forced, _aux=aux2, **meta)
+    chk["fine_points_bit_exact"] = bool(np.array_equal(aux2["fine_points"][0].cpu().numpy(), r0["fine_points"]))
+    f_a, f_r = aux2["fine_rgb_sigma"][0].cpu().numpy(), r0["fine_rgb_sigma"]
+    chk["fine_rgb_sigma_err"] = max(scaled_err(f_a[..., :3], f_r[..., :3]), scaled_err(f_a[..., 3], f_r[..., 3]))
+    chk["sort_idx_equal"] = bool(np.array_equal(aux2["sort_idx"][0].cpu().numpy().astype(np.int64), r0["sort_idx"]))
+    chk["pixels_err_forced"] = scaled_err(px2[0].cpu().numpy(), ref.pixels[0].numpy())
+    chk["depth_err_forced"] = scaled_err(dp2[0].cpu().numpy(), ref.depth[0].numpy())
+    chk["pixels_survey_metric_pass"] = survey_metric_pass(px2[0].cpu().numpy(), ref.pixels[0].numpy())
+    tol = 1e-4 if args.precision == "fp32" else 2e-4
+    chk["tolerance"] = tol
+    chk["pass"] = bool(chk["timed_output_reproduced"] and chk["points_bit_exact"] and chk["fine_points_bit_exact"] and
+                       chk["rgb_sigma_err"] < 1e-4 and chk["fine_rgb_sigma_err"] < 1e-4 and chk["inds_equal"] > 0.99 and
+                       chk["sort_idx_equal"] and chk["pixels_err_forced"] < tol and chk["depth_err_forced"] < tol and
+                       chk["pixels_mean_abs_err_free_running"] < 2e-3)
+    chk["what"] = ("image 0 of the last timed step (draws from torch.cuda seed %d) vs oracle/render_oracle.py on the same inputs and "
+                   "draws; *_forced: oracle's fine depths injected" % CHECK_SEED)
+    return chk
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def stub_main(args, rank, world):
+    """`--device cpu`: the launcher / timing / aggregation path on gloo with a stand-in step (the render has no CPU path).
+    Used by tests/test_distributed_cpu.py; never a benchmark -- the line says so."""
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    elapsed = timed_region(lambda i: time.sleep(0.005 * (1 + rank)), args.steps, args.warmup, dist if world > 1 else None)
+    if rank == 0:
+        print(json.dumps({"metric": "rays/sec at 128x128x64spp ShapeNetCar", "unit": "rays/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "value": whole_job_rays_per_s(world, args.batch, args.img_size, args.steps, elapsed),
+                          "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                          "dtype": "none", "data": "stub: stand-in step on the CPU (launcher test), NOT a measurement",
+                          "config": {"workload": "stub"}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
 
 
 def main():
@@ -220,18 +417,21 @@ def main():
     ap.add_argument("--noise", type=float, default=0.0)
     ap.add_argument("--precision", default="fp32", choices=["fp32", "fp16x3"],
                     help="arithmetic of the MLP products: exact fp32 MFMA, or the fp32-accurate fp16x3 split")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle leg (and with it the check of the timed image)")
     ap.add_argument("--no-fast-path", action="store_true", help="skip the secondary fp16x3 measurement")
+    ap.add_argument("--no-train-step", action="store_true", help="skip the secondary forward + backward measurement")
     ap.add_argument("--cpu-reps", type=int, default=2)
+    ap.add_argument("--device", default="cuda", choices=["cuda", "cpu"], help="cpu: launcher test with a stand-in step (no measurement)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_children(args.gpus, sys.argv[1:])          # nothing above has touched the GPU
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+    args.gpus = world
+    if args.device == "cpu":
+        return stub_main(args, rank, world)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -247,6 +447,7 @@ def main():
         dist.barrier()
     import cnerf_amd
     from cnerf_amd.generators import ImplicitGenerator3d
+    from cnerf_amd.generators.generators import draw_rng
 
     torch.manual_seed(0)                                      # reference default init under seed 0
     gen_cpu = ImplicitGenerator3d(args.variant, args.z_dim, args.input_dim, 4, args.hidden)
@@ -258,28 +459,33 @@ def main():
     B, R, S = args.batch, args.img_size, args.num_steps
     fvol, glob, cam = synthetic_inputs(B, args.volume, args.z_dim, dev, seed=rank)
     meta = dict(clamp_mode="relu", nerf_noise=args.noise, white_back=True, hierarchical_sample=True)
-    meta_nohier = dict(meta)
+
+    # The draws of the LAST timed step are known in advance (torch.cuda seed CHECK_SEED), so the CPU oracle can render the
+    # expected image of that step first: CPU leg, then the GPU legs.
+    do_check = world == 1 and not args.no_cpu_baseline
+    base = ref = draws = None
+    if do_check:
+        torch.cuda.manual_seed(CHECK_SEED)
+        draws = draw_rng(B, R * R, S, True, args.noise, dev)
+        base, ref = cpu_baseline(args, gen_cpu, fvol, glob, cam, draws)
 
     evs = HipEvents()
-    n_ev = 4 * args.steps
-    events = evs.create(n_ev)
+    events = evs.create(4 * args.steps)
+    last = {}
 
     def step(i=None):
         ev = events[4 * i:4 * i + 4] if i is not None else None
-        cnerf_amd.ops._pack_cache.clear()                     # training changes the weights every step: re-pack
+        cnerf_amd.ops.clear_pack_cache()                      # training changes the weights every step: re-pack
+        if i == args.steps - 1:
+            torch.cuda.manual_seed(CHECK_SEED)                # host-side generator state only: no device work, no sync
         with torch.no_grad():
-            return gen(zin(gen, fvol, glob), cam, R, FOV, RAY_START, RAY_END, S, _field_events=ev, **meta)
+            last["out"] = gen(zin(gen, fvol, glob), cam, R, FOV, RAY_START, RAY_END, S, _field_events=ev, **meta)
 
-    last = {}
-
-    def step_i(i):
-        last["out"] = step(i)
-
-    elapsed = timed_region(step_i, args.steps, args.warmup, dist if world > 1 else None, torch.cuda.synchronize, dev)
+    elapsed = timed_region(step, args.steps, args.warmup, dist if world > 1 else None, torch.cuda.synchronize, dev)
     out = last["out"]
-    assert torch.isfinite(out[0]).all()
+    assert torch.isfinite(out[0]).all() and torch.isfinite(out[1]).all()
 
-    # dominant kernel: field_tile_kernel, two launches per step (coarse, fine), same work each
+    # dominant kernel: the field kernel, two launches per step (coarse, fine), same work each
     kern_ms = []
     for i in range(args.steps):
         e = events[4 * i:4 * i + 4]
@@ -291,23 +497,23 @@ def main():
     split = args.precision == "fp16x3"
     if split:      # priced per issued flop: three fp16 MFMAs per fp32 product, against the dense fp16 MFMA peak
         roof = {"kernel": "field_h3_kernel<8> (sample + trilinear lookup + FiLM-SIREN MLP, fp16x3 split, fp32 accumulate)",
-                "bound": "mfma", "achieved": 3 * achieved, "peak": 2500.0, "unit": "TFLOP/s", "frac": 3 * achieved / 2500.0,
-                "traffic": None, "algorithmic_tflops": achieved}
+                "bound": "mfma", "achieved": 3 * achieved, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": 3 * achieved / PEAK_F16_MFMA_TFLOPS, "traffic": None, "algorithmic_tflops": achieved}
+        pk = pmc_bytes("void cnerf::field_h3_kernel")
     else:
         roof = {"kernel": "field_tile_kernel<8> (sample + trilinear lookup + FiLM-SIREN MLP, fp32 MFMA)",
                 "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None}
-    # HBM bytes cannot be counted from inside this process.  `traffic` is the rocprofv3 PMC measurement of the same kernels on
-    # the same workload shape at batch 2 (scripts/pmc_traffic.sh -> profiles/r01_field_kernel_profile.md: FETCH_SIZE 31,290 KB
-    # x 2 for gfx950's wide reads + WRITE_SIZE 36,860 KB per launch of 2,097,152 points, identical for both field kernels =
-    # 48.5 B per point: the channel-last volumes read once, rgb_sigma and z written once) scaled to this launch's points.
-    PMC_BYTES_PER_POINT = (2 * 31290.0 + 36860.0) * 1024.0 / 2097152.0
-    roof["traffic"] = PMC_BYTES_PER_POINT * B * R * R * S if (R, S, args.volume) == (128, 64, 64) else None
-    roof["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE at batch 2 (profiles/r01_field_kernel_profile.md), scaled by points per launch"
+        pk = pmc_bytes("void cnerf::field_tile_kernel")
+    # HBM bytes cannot be counted from inside this process: `traffic` is the rocprofv3 PMC measurement of the same kernel
+    # on the same workload shape (profiles/pmc_traffic.json), per point, scaled to this launch's points.
+    if pk and (R, S, args.volume) == (128, 64, 64):
+        roof["traffic"] = pk["bytes_per_point"] * B * R * R * S
+        roof["traffic_source"] = f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes ({os.path.relpath(PMC_FILE, ROOT)}), per point x points per launch"
     roof.update({"avg_launch_ms": avg_ms, "launches": len(kern_ms), "flops_per_launch": flops_per_launch,
-
                  "share_of_step": 2 * avg_ms / (elapsed / args.steps * 1e3)})
 
+    rc = 0
     if rank == 0:
         rays = world * B * R * R * args.steps
         res = {
@@ -322,17 +528,25 @@ def main():
                        "parallelism": f"image-batch data parallel x{world}, no data-path collective"},
             "roofline": roof,
         }
+        if do_check:
+            res["check"] = check_against_oracle(args, gen, fvol, glob, cam, meta, draws, ref, out[0], out[1])
+            res["cpu_baseline"] = base
+            if not res["check"]["pass"]:
+                rc = 1
         if world == 1:
             res["roofline_sample_composite"] = sample_composite_pass(args, gen, fvol, glob, cam, meta, evs)
         if world == 1 and args.precision == "fp32" and not args.no_fast_path:
             res["fp16x3_split_path"] = fast_path(args, gen, fvol, glob, cam, meta, evs)
-        if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(args, gen_cpu)
+        if world == 1 and not args.no_train_step:
+            res["train_step"] = train_step_timing(args, gen, fvol, glob, cam, evs)
         print(json.dumps(res), flush=True)
+        if rc:
+            sys.stderr.write("bench.py: the timed image FAILED the oracle check: " + json.dumps(res["check"]) + "\n")
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    return rc
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

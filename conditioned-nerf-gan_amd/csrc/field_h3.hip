@@ -613,11 +613,8 @@ static hipError_t launch_h3_inst(const FieldArgs& a, hipStream_t stream) {
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
     const size_t lds_bytes = h3_lds_bytes<NT>(a, PAIRED ? 4 : 2);
     if (lds_bytes > LDS_LIMIT) return hipErrorInvalidValue;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipError_t e = hipFuncSetAttribute((const void*)field_h3_kernel<NT, STORE, PAIRED, HAS_RES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT)) return e;
-        attr_set = true;
-    }
+    // (per launch, not once per process: the attribute is per device, and a cached flag would be unsynchronised global state)
+    if (hipError_t e = hipFuncSetAttribute((const void*)field_h3_kernel<NT, STORE, PAIRED, HAS_RES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT)) return e;
     const long long want = (a.total_tiles / a.tiles_per_image) * ((a.tiles_per_image + 3) / 4), cap = (long long)cus;
     int blocks = (int)(want < cap ? want : cap);
     if (blocks < 8) blocks = 8;

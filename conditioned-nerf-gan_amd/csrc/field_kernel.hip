@@ -870,11 +870,9 @@ static hipError_t launch_field_tile(const FieldArgs& a, hipStream_t stream) {
     if (a.n_in < 1 || a.in_level[0] < 0) return hipErrorInvalidValue;      // the lookup prefetch assumes a volume tile first
     const void* fn = (const void*)field_tile_kernel<NT, HAS_RES, STORE>;
     const int lds_bytes = (CNERF_F32_LOOKUP_DMA && NT >= 4) ? 4 * 32 * 1024 : 0;   // lookup staging of the four waves
-    static bool attr_set = false;
-    if (lds_bytes && !attr_set) {
+    // (per launch, not once per process: the attribute is per device, and a cached flag would be unsynchronised global state)
+    if (lds_bytes)
         if (hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)) return e;
-        attr_set = true;
-    }
     const int blocks = lds_bytes ? field_grid_one_per_cu(a.total_tiles) : field_grid(fn, a.total_tiles);
     hipLaunchKernelGGL((field_tile_kernel<NT, HAS_RES, STORE>), dim3(blocks), dim3(256), lds_bytes, stream, a);
     return hipGetLastError();

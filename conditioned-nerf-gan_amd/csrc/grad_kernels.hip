@@ -139,11 +139,7 @@ template <int NJ>
 static hipError_t launch_wg(const WeightGradArgs& a, hipStream_t stream) {
     const unsigned row_groups = (unsigned)((a.H + 127) / 128);     // 4 waves x one 32-row tile per block
     const int lds_bytes = 2 * (WG_P * 32 * NJ + WG_P * 128) * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipError_t e = hipFuncSetAttribute((const void*)weight_grad_kernel<NJ>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)) return e;
-        attr_set = true;
-    }
+    if (hipError_t e = hipFuncSetAttribute((const void*)weight_grad_kernel<NJ>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)) return e;
     hipLaunchKernelGGL((weight_grad_kernel<NJ>), dim3((unsigned)(a.cnt * a.blocks_per_image), row_groups), dim3(256), lds_bytes, stream, a);
     return hipGetLastError();
 }

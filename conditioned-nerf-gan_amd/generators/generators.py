@@ -12,6 +12,24 @@ from . import siren
 from .. import ops
 
 
+def draw_rng(B, P, S, hierarchical, noise_std, dev):
+    """The random tensors of one forward, drawn with the reference's shapes and in its order (rand (B,P,S,1),
+    randn (B,P,S,1), rand (B*P,S), randn (B,P,2S,1)), so the torch generator advances exactly as it does there; the noise
+    tensors are drawn even when nerf_noise == 0 (volumetric_rendering.py:39) and only handed on when they are used."""
+    rng = {"u_strat": torch.rand((B, P, S, 1), device=dev)}
+    if hierarchical:
+        eps_c = torch.randn((B, P, S, 1), device=dev)
+        rng["u_fine"] = torch.rand((B * P, S), device=dev)
+        eps_f = torch.randn((B, P, 2 * S, 1), device=dev)
+        if noise_std != 0:
+            rng["eps_coarse"], rng["eps_final"] = eps_c, eps_f
+    else:
+        eps_f = torch.randn((B, P, S, 1), device=dev)
+        if noise_std != 0:
+            rng["eps_final"] = eps_f
+    return rng
+
+
 class ImplicitGenerator3d(nn.Module):
     def __init__(self, siren_type, z_dim, input_dim, output_dim, hidden_dim, drop_out=0):
         super().__init__()
@@ -44,20 +62,7 @@ class ImplicitGenerator3d(nn.Module):
         freq, phase = net.film(glob)
         rng = kwargs.get("_rng")
         if rng is None:
-            # same draws, shapes and order as the reference, so the torch generator advances
-            # identically; the noise tensors are drawn even when nerf_noise == 0 (volumetric_rendering.py:39)
-            P = R * R
-            rng = {"u_strat": torch.rand((B, P, S, 1), device=dev)}
-            if hierarchical_sample:
-                eps_c = torch.randn((B, P, S, 1), device=dev)
-                rng["u_fine"] = torch.rand((B * P, S), device=dev)
-                eps_f = torch.randn((B, P, 2 * S, 1), device=dev)
-                if noise_std != 0:
-                    rng["eps_coarse"], rng["eps_final"] = eps_c, eps_f
-            else:
-                eps_f = torch.randn((B, P, S, 1), device=dev)
-                if noise_std != 0:
-                    rng["eps_final"] = eps_f
+            rng = draw_rng(B, R * R, S, bool(hierarchical_sample), noise_std, dev)
         aux_out = kwargs.get("_aux")
         pixels, depth, aux = ops.render(net, fvol, freq, phase, cam2worlds, R, fov, ray_start, ray_end, S,
                                         bool(hierarchical_sample), clamp_mode, noise_std, white_back, last_back, rng,

@@ -1,14 +1,24 @@
 """Thin PyTorch-side wrappers over the C ABI (include/cnerf.h).  PyTorch only provides device memory, the current
 stream and autograd plumbing here; every computation below happens in libcnerf_hip.so."""
 import ctypes as C
-from typing import Dict, Optional
+import weakref
+from typing import Optional
 
 import torch
 import torch.nn.functional as F
 
 from . import _lib as L
 
-_pack_cache: Dict[int, tuple] = {}
+# packed weights per field network: dropped with the module (weak keys), re-packed when a parameter's version changes
+_pack_cache = weakref.WeakKeyDictionary()
+_packt_cache = weakref.WeakKeyDictionary()
+
+
+def clear_pack_cache():
+    """Forget every packed weight buffer (a training step that changed the weights re-packs anyway: the cache keys hold the
+    parameters' version counters; bench.py calls this so that every timed step pays the packing like a training step)."""
+    _pack_cache.clear()
+    _packt_cache.clear()
 
 
 def _stream():
@@ -112,7 +122,7 @@ def pack_field(net, cfg):
     """Packed MFMA-order weights of `net` (device tensor), re-packed only when a parameter changed."""
     params = [_f32(p.detach()) for p in net.field_params()]
     key = tuple((p.data_ptr(), p._version) for p in net.field_params()) + (cfg.precision,)
-    hit = _pack_cache.get((id(net), cfg.precision))
+    hit = _pack_cache.setdefault(net, {}).get(cfg.precision)
     if hit is not None and hit[0] == key:
         return hit[1]
     nbytes, _, _ = sizes(cfg, render=False)
@@ -120,7 +130,7 @@ def pack_field(net, cfg):
     fp = _field_params_struct(net, params)
     L.check(L.lib().cnerf_pack_field(C.byref(cfg), C.byref(fp), L.ptr(packed), _stream()), "cnerf_pack_field")
     packed._keepalive = params
-    _pack_cache[(id(net), cfg.precision)] = (key, packed)
+    _pack_cache[net][cfg.precision] = (key, packed)
     return packed
 
 
@@ -274,14 +284,13 @@ def render_forward(net, fvol, freq, phase, cam2world, img_size, fov, ray_start, 
 # ---------------------------------------------------------------------------------------------------------------------
 # autograd
 # ---------------------------------------------------------------------------------------------------------------------
-_packt_cache: Dict[int, tuple] = {}
 SAVED_KEYS = ("coarse_rgb_sigma", "coarse_z", "fine_rgb_sigma", "fine_z")
 
 
 def pack_field_transposed(net, cfg):
     params = [_f32(p.detach()) for p in net.field_params()]
     key = tuple((p.data_ptr(), p._version) for p in net.field_params())
-    hit = _packt_cache.get(id(net))
+    hit = _packt_cache.get(net)
     if hit is not None and hit[0] == key:
         return hit[1]
     nb = C.c_size_t(0)
@@ -291,7 +300,7 @@ def pack_field_transposed(net, cfg):
     L.check(L.lib().cnerf_pack_field_transposed(C.byref(cfg), C.byref(fp), L.ptr(packed_t), _stream()),
             "cnerf_pack_field_transposed")
     packed_t._keepalive = params
-    _packt_cache[id(net)] = (key, packed_t)
+    _packt_cache[net] = (key, packed_t)
     return packed_t
 
 

@@ -28,25 +28,44 @@ def load_cam2world(cameras_npz, view):
     return m
 
 
-CHECKPOINT_KEYS = ("step", "generator_state_dict", "optimizer_G_state_dict", "encoder_state_dict", "optimizer_E_state_dict",
-                   "discriminator_state_dict", "optimizer_D_state_dict")
+# every key Trainer.save_models writes (utils.py:473-501) and Trainer.load_models reads back unconditionally
+# (utils.py:318-336, 407-410): a file without one of them raises KeyError in the reference's loader
+CHECKPOINT_KEYS = ("step", "generator_state_dict", "optimizer_G_state_dict", "scaler_state_dict", "encoder_state_dict",
+                   "optimizer_E_state_dict", "photometry_losses_val", "depth_losses_val", "photometry_losses_test",
+                   "depth_losses_test")
+DISCRIMINATOR_KEYS = ("discriminator_state_dict", "optimizer_D_state_dict", "generator_losses", "discriminator_losses")
+
+
+def _fresh_scaler_state():
+    """state_dict() of an untouched torch.cuda.amp.GradScaler (what the reference's loader hands to scaler.load_state_dict,
+    utils.py:336).  This harness trains in fp32 and has no scaler; the dict is spelled out because constructing a GradScaler
+    on a machine without a GPU warns and disables itself (its state_dict is then empty)."""
+    return {"scale": 65536.0, "growth_factor": 2.0, "backoff_factor": 0.5, "growth_interval": 2000, "_growth_tracker": 0}
 
 
 def save_checkpoint(trainer, directory):
-    """`<step>.tar` with the reference's key names (utils.py:473-501), so either code base can resume the other's run.  The
-    reference also stores its AMP `scaler_state_dict` and loss histories; this harness trains in fp32 and keeps the losses."""
+    """`<step>.tar` with the key set of the reference's Trainer.save_models (utils.py:473-501), so that either code base can
+    resume the other's run: the reference's loader reads `scaler_state_dict` and the four validation / test loss histories
+    unconditionally, so they are written too (a fresh GradScaler state -- this harness trains in fp32 -- and the histories
+    the trainer carries, empty when it never evaluated)."""
     step = int(trainer.generator.step)
+    hist = getattr(trainer, "eval_losses", {})
     ck = {"step": step,
           "generator_state_dict": trainer.generator.state_dict(),
           "optimizer_G_state_dict": trainer.optimizer_G.state_dict(),
+          "scaler_state_dict": _fresh_scaler_state(),
           "encoder_state_dict": trainer.encoder.state_dict(),
           "optimizer_E_state_dict": trainer.optimizer_E.state_dict(),
-          "generator_losses": list(trainer.losses["g"]),
-          "discriminator_losses": list(trainer.losses["d"]),
-          "photometry_losses": list(trainer.losses["photo"])}
+          "photometry_losses": list(trainer.losses["photo"]),
+          "photometry_losses_val": list(hist.get("photometry_losses_val", [])),
+          "depth_losses_val": list(hist.get("depth_losses_val", [])),
+          "photometry_losses_test": list(hist.get("photometry_losses_test", [])),
+          "depth_losses_test": list(hist.get("depth_losses_test", []))}
     if trainer.metadata.get("enable_discriminator", True):
         ck["discriminator_state_dict"] = trainer.discriminator.state_dict()
         ck["optimizer_D_state_dict"] = trainer.optimizer_D.state_dict()
+        ck["generator_losses"] = list(trainer.losses["g"])
+        ck["discriminator_losses"] = list(trainer.losses["d"])
     os.makedirs(directory, exist_ok=True)
     path = os.path.join(directory, f"{step}.tar")
     torch.save(ck, path)
@@ -54,8 +73,9 @@ def save_checkpoint(trainer, directory):
 
 
 def load_checkpoint(trainer, path, map_location=None):
-    """Resume from a `<step>.tar` written by save_checkpoint or by the reference's Trainer.save_models (utils.py:296-330 reads
-    the same keys back).  Loaded with weights_only=True: nothing in the file is executed."""
+    """Resume from a `<step>.tar` written by save_checkpoint or by the reference's Trainer.save_models (same keys; the AMP
+    scaler state of a reference file is ignored: fp32 training).  Model / optimizer states, the step counter and the loss
+    histories are restored.  Loaded with weights_only=True: nothing in the file is executed."""
     ck = torch.load(path, map_location=map_location or trainer.device, weights_only=True)
     trainer.generator.load_state_dict(ck["generator_state_dict"], strict=True)
     trainer.encoder.load_state_dict(ck["encoder_state_dict"], strict=True)
@@ -66,4 +86,8 @@ def load_checkpoint(trainer, path, map_location=None):
         trainer.optimizer_D.load_state_dict(ck["optimizer_D_state_dict"])
     trainer.generator.step = int(ck["step"])          # (utils.py:318: the reference resumes at the stored step as well)
     trainer.discriminator.step = int(ck["step"])
+    trainer.losses = {"g": list(ck.get("generator_losses", [])), "d": list(ck.get("discriminator_losses", [])),
+                      "photo": list(ck.get("photometry_losses", []))}
+    trainer.eval_losses = {k: list(ck.get(k, [])) for k in ("photometry_losses_val", "depth_losses_val", "photometry_losses_test",
+                                                            "depth_losses_test")}
     return ck

@@ -1,16 +1,20 @@
 #!/usr/bin/env python3
-"""Small fixed workload for rocprofv3 runs: a few ImplicitGenerator3d.forward calls at 128x128x64 (B images),
-nothing else on the GPU.  Usage: rocprofv3 ... -- python3 scripts/profile_workload.py [B] [calls]"""
+"""Small fixed workload for rocprofv3 runs: a few ImplicitGenerator3d.forward calls at 128x128x64 (B images), then the
+unfused sample + composite pass of SURVEY.md 8(d) on the same samples (cnerf_gather_features over every coarse and fine
+point, cnerf_composite over the merged samples), nothing else on the GPU.
+Usage: rocprofv3 ... -- python3 scripts/profile_workload.py [B] [calls]      (CNERF_PRECISION=fp32|fp16x3)"""
 import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import cnerf_amd
+from cnerf_amd import ops
 from cnerf_amd.generators import ImplicitGenerator3d
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 calls = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+R, S = 128, 64
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 gen = ImplicitGenerator3d("SHORTSIREN_FG", 256, 32, 4, 256).to(dev)
@@ -19,9 +23,20 @@ gen.siren.precision = os.environ.get("CNERF_PRECISION", "fp32")
 fvol, glob = torch.randn(B, 32, 64, 64, 64, device=dev), torch.randn(B, 256, device=dev)
 cam = torch.eye(4, device=dev).unsqueeze(0).repeat(B, 1, 1)
 cam[:, 2, 3] = -1.0
+aux = {}
 with torch.no_grad():
     for _ in range(calls):
-        px, dp = gen((fvol, glob), cam, 128, 49.134342641202636, 0.25, 1.95, 64, True, clamp_mode="relu", nerf_noise=0.0,
-                     white_back=True)
+        px, dp = gen((fvol, glob), cam, R, 49.134342641202636, 0.25, 1.95, S, True, clamp_mode="relu", nerf_noise=0.0,
+                     white_back=True, _aux=aux)
+    fcl = ops.channel_last(fvol)
+    pts = torch.cat([aux["coarse_points"].reshape(B, -1, 3), aux["fine_points"].reshape(B, -1, 3)], 1).contiguous()
+    allz = torch.cat([aux["fine_z"], aux["coarse_z"]], -1)
+    allrs = torch.cat([aux["fine_rgb_sigma"], aux["coarse_rgb_sigma"]], -2)
+    idx = aux["sort_idx"].long()
+    zs = torch.gather(allz, -1, idx).reshape(B * R * R, 2 * S).contiguous()
+    rss = torch.gather(allrs, -2, idx.unsqueeze(-1).expand(-1, -1, -1, 4)).reshape(B * R * R, 2 * S, 4).contiguous()
+    for _ in range(calls):
+        ops.gather_features(gen.siren, fcl, pts)
+        ops.composite(rss, zs, None, 0.0, "relu", True, False)
 torch.cuda.synchronize()
-print("ok", float(px.mean()), float(dp.mean()))
+print("ok", float(px.mean()), float(dp.mean()), "points per field launch", B * R * R * S, "gather points", pts.shape[0] * pts.shape[1])

@@ -86,6 +86,17 @@ FIXTURES = {
     "tallsiren_small": dict(variant="TALLSIREN", B=1, R=12, S=8, V=10, C=32, H=64, Z=32,
                             noise=0.0, clamp="relu", white_back=True, last_back=False, seed=13, full=True,
                             grads=True),
+    # the deepest residual chain: sine + 4 residual blocks + sine (siren.py:411-488)
+    "tall_dreslong_small": dict(variant="TALLSIREN_dResLong", B=1, R=12, S=12, V=10, C=32, H=64, Z=32,
+                                noise=0.0, clamp="relu", white_back=True, last_back=False, seed=14, full=True,
+                                grads=True),
+    # A WELL-CONDITIONED scene for free-running parity (no teacher forcing): smooth feature volume (a 3^3 grid upsampled
+    # trilinearly), mild head, softplus density -> every importance bin carries mass, the field varies slowly along a ray, and
+    # the reference's own fp32 result sits ~1e-6 from exact arithmetic (the other fixtures: 1e-3 .. 1e-1, see
+    # tests/test_gpu_parity.py::test_free_running_noise_floor).
+    "short_fg_smooth": dict(variant="SHORTSIREN_FG", B=2, R=16, S=12, V=16, C=32, H=64, Z=48,
+                            noise=0.0, clamp="softplus", white_back=True, last_back=False, seed=22, full=True,
+                            grads=False, head=(3.0, 5.0, 0.5), smooth_from=3, amp=0.3),
 }
 
 # variants whose `z` is the bare feature volume (no global feature)
@@ -117,12 +128,17 @@ def build(name):
     # Default init gives near-zero densities (an all-background image pins nothing): scale the head so
     # that sigma spans both signs at O(1..10) and colours leave the sigmoid's linear range.  The scaled
     # values are stored in the fixture like every other parameter.
+    head = spec.get("head", (6.0, 40.0, 0.25))
     with torch.no_grad():
-        gen.siren.final_layer.weight[:3] *= 6.0
-        gen.siren.final_layer.weight[3] *= 40.0
-        gen.siren.final_layer.bias[3] += 0.25
+        gen.siren.final_layer.weight[:3] *= head[0]
+        gen.siren.final_layer.weight[3] *= head[1]
+        gen.siren.final_layer.bias[3] += head[2]
 
-    fvol = (torch.randn(B, C, V, V, V) * 0.5).requires_grad_(True)
+    if "smooth_from" in spec:
+        low = torch.randn(B, C, spec["smooth_from"], spec["smooth_from"], spec["smooth_from"]) * spec["amp"]
+        fvol = F.interpolate(low, size=(V, V, V), mode="trilinear", align_corners=True).requires_grad_(True)
+    else:
+        fvol = (torch.randn(B, C, V, V, V) * 0.5).requires_grad_(True)
     pyr = None
     if "pyramid" in spec:
         pyr = [fvol] + [(torch.randn(B, c, v, v, v) * 0.5).requires_grad_(True) for c, v in spec["pyramid"][1:]]

@@ -59,3 +59,36 @@ def test_single_process_region():
     n = []
     t = bench.timed_region(lambda i: n.append(i), steps=3, warmup=1)
     assert n == [None, 0, 1, 2] and t >= 0
+
+
+@pytest.mark.timeout(180)
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment (the form the driver's N=1 command takes with N
+    changed): the parent starts two ranks through torch.distributed.run as CHILD processes, relays rank 0's single JSON
+    line and their exit code.  `--device cpu` swaps the render for a stand-in step on gloo (no GPU here); everything else
+    -- launcher, rendezvous on 127.0.0.1, barrier, max-over-ranks, whole-job aggregation -- is the code the GPU run uses."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--device", "cpu"],
+                       capture_output=True, text=True, env=env, timeout=170)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, p.stdout
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["steps"] == 4 and res["warmup"] == 1 and res["scaling"] == "weak"
+    assert res["ms_per_step"] >= 10.0 * 0.9                  # the slower rank (rank 1: 10 ms per step) sets the time
+    assert abs(res["value"] - 2 * 8 * 128 * 128 / (res["ms_per_step"] * 1e-3)) < 1e-6 * res["value"]
+    assert "stub" in res["data"]
+
+
+def test_bench_launcher_propagates_failure():
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "0", "--device", "cpu"],
+                       capture_output=True, text=True, env=env, timeout=170)
+    assert p.returncode != 0 and not p.stdout.strip()        # steps = 0 divides by zero in every rank: no line, non-zero exit

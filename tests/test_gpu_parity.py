@@ -259,6 +259,94 @@ def test_render_free_running(golden, dev, name):
     assert np.abs(depth - g["depth"]).mean() < 2e-3
 
 
+def err_stats(a, b):
+    d = np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).ravel()
+    return {"mean": float(d.mean()), "p999": float(np.quantile(d, 0.999)), "max": float(d.max())}
+
+
+def oracle_free_running(g, dtype):
+    """The oracle on a fixture's inputs and draws WITHOUT forcing anything, in float32 or float64."""
+    from oracle import render_oracle as O
+    m = g.meta
+    T = lambda x: None if x is None else torch.from_numpy(np.asarray(x)).to(dtype)
+    vols = g.volumes()
+    fvol = [T(v) for v in vols] if isinstance(vols, list) else T(vols)
+    torch.set_default_dtype(dtype)
+    try:
+        with torch.no_grad():
+            return O.render(m["variant"], {k: T(v) for k, v in g.params().items()}, fvol, T(g.get("global_feature")), T(g["cam2worlds"]),
+                            m["R"], m["fov"], m["ray_start"], m["ray_end"], m["S"], True, m["clamp"], m["noise"], m["white_back"],
+                            m["last_back"], T(g["u_strat"]), T(g.get("eps_coarse")), T(g.get("u_fine")), T(g.get("eps_final")))
+    finally:
+        torch.set_default_dtype(torch.float32)
+
+
+def free_running_floor(g):
+    """How far the reference's OWN arithmetic is from exact on a free-running render: the fp32 oracle (bit-identical to the
+    reference on the fixtures, tests/test_oracle_golden.py) against the same oracle in float64 -- identical inputs, draws
+    and algorithm, only the rounding differs.  Error statistics of pixels and depth."""
+    a, b = oracle_free_running(g, torch.float32), oracle_free_running(g, torch.float64)
+    return err_stats(a.pixels, b.pixels), err_stats(a.depth, b.depth)
+
+
+HIER_FIXTURES = [n for n in GOLDEN_NAMES if n not in ("short_fg_nohier", "short_fg_smooth")]
+
+
+@pytest.mark.parametrize("name", HIER_FIXTURES)
+def test_free_running_noise_floor(golden, dev, name):
+    """Evidence behind the teacher forcing of the image-level tests.  A free-running render (nothing forced) of the HIP path
+    differs from the reference's by MORE than 1e-4 on these fixtures -- and so does the reference from itself once only the
+    rounding changes: its fp32 result against the same algorithm in float64 (`free_running_floor`) is off by 1e-4 .. 1e-1
+    on single pixels, because the 1e-7-level rounding of the coarse densities moves resampled depths that fall into
+    near-empty importance bins, and the random-init SIREN turns the shift into a colour change.  The HIP path must sit
+    inside that floor: mean and 99.9th-percentile pixel / depth error no more than 3x the reference's own fp32-vs-fp64
+    figures (+1e-6 absolute), worst pixel no more than 10x the reference's worst pixel."""
+    g = golden(name)
+    pixels, depth, aux = _render_with(g, dev, forced=False)
+    f_px, f_dp = free_running_floor(g)
+    h_px, h_dp = err_stats(pixels, g["pixels"]), err_stats(depth, g["depth"])
+    print(f"{name}: pixels HIP-vs-reference {h_px} | reference fp32-vs-fp64 {f_px}")
+    print(f"{name}: depth  HIP-vs-reference {h_dp} | reference fp32-vs-fp64 {f_dp}")
+    for h, f in ((h_px, f_px), (h_dp, f_dp)):
+        assert h["mean"] <= 3 * f["mean"] + 1e-6
+        assert h["p999"] <= 3 * f["p999"] + 1e-6
+        assert h["max"] <= 10 * f["max"] + 1e-5
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fp16x3"])
+def test_free_running_well_conditioned(golden, dev, precision):
+    """`short_fg_smooth`: a fixture of the reference where free-running parity is a fair question -- smooth feature volume,
+    mild head, softplus density, so every importance bin carries mass and the reference's own fp32-vs-fp64 distance is
+    ~1e-6.  NOTHING is forced here: the whole hierarchical render (coarse pass, resampling, fine pass, merge, composite)
+    runs on its own and the image, the depth map, the resampled depths and both rgb/sigma tensors agree with the reference
+    to the north-star tolerance; bins and merge order bit for bit."""
+    g = golden("short_fg_smooth")
+    m = g.meta
+    f_px, f_dp = free_running_floor(g)
+    assert f_px["max"] < 2e-5 and f_dp["max"] < 2e-5          # the scene is well conditioned for the reference itself
+    gen = make_generator(g, dev)
+    gen.siren.precision = precision
+    z, _, _ = make_z(g, dev)
+    rng = {k: G(g[k], dev) for k in ("u_strat", "u_fine")}
+    aux = {}
+    with torch.no_grad():
+        pixels, depth = gen(z, G(g["cam2worlds"], dev), m["R"], m["fov"], m["ray_start"], m["ray_end"], m["S"], True,
+                            clamp_mode=m["clamp"], nerf_noise=m["noise"], white_back=m["white_back"], last_back=m["last_back"],
+                            _rng=rng, _aux=aux)
+    aux = {k: v.cpu().numpy() for k, v in aux.items()}
+    assert np.array_equal(aux["coarse_points"], g["coarse_points"])
+    assert np.array_equal(aux["inds"], g["inds"].astype(np.int32))
+    assert np.array_equal(aux["sort_idx"], g["sort_idx"].astype(np.int32))
+    assert scaled_err(aux["fine_z"], g["fine_z"]) < 1e-5
+    assert scaled_err(aux["coarse_rgb_sigma"], g["coarse_rgb_sigma"]) < TOL
+    assert scaled_err(aux["fine_rgb_sigma"], g["fine_rgb_sigma"]) < TOL
+    e_p, e_d = scaled_err(pixels.cpu().numpy(), g["pixels"]), scaled_err(depth.cpu().numpy(), g["depth"])
+    print(f"short_fg_smooth free-running [{precision}]: pixels {e_p:.2e} depth {e_d:.2e}; survey-metric pass "
+          f"{survey_metric_pass(pixels.cpu().numpy(), g['pixels']):.4f}")
+    assert e_p < TOL and e_d < TOL
+    assert np.abs(pixels.cpu().numpy() - g["pixels"]).max() < 1e-4      # absolute, too: |pixels| <= 0.2 here
+
+
 GRAD_FIXTURES = [n for n in GOLDEN_NAMES if n.endswith("_small") or n in ("short_fg_nohier", "short_fg_s40")]
 RES_FIXTURES = set(NO_BACKWARD_YET)      # (residual-block networks have a backward too)
 
@@ -388,48 +476,82 @@ def test_render_matches_oracle_random_inputs(dev, precision):
 
 
 def _oracle_case(dev, variant, B, R, S, V, H, clamp="relu", noise=0.0, white=True, last=False, seed=0, check_grads=False,
-                 precision="fp32"):
-    """Random inputs of an arbitrary shape: HIP vs the CPU oracle on the same rays / draws, fine depths forced."""
+                 precision="fp32", Z=32, head_scale=30.0):
+    """Random inputs of an arbitrary shape: HIP vs the CPU oracle on the same rays / draws, fine depths forced.
+    `precision` may be a tuple: every listed forward kernel is checked against the one oracle run."""
     import cnerf_amd
     from cnerf_amd.generators import ImplicitGenerator3d
     from cnerf_amd.generators.volumetric_rendering import sample_camera_positions, create_cam2world_matrix
     from oracle import render_oracle as O
     torch.manual_seed(seed)
     np.random.seed(seed)
-    Z = 32
     has_glob = O.FIELD_SPECS[variant].has_global
     gen = ImplicitGenerator3d(variant, Z if has_glob else 32, 32, 4, H)
     with torch.no_grad():
-        gen.siren.final_layer.weight[3] *= 30
+        gen.siren.final_layer.weight[3] *= head_scale
     fvol, glob = torch.randn(B, 32, V, V, V) * 0.5, (torch.randn(B, Z) if has_glob else None)
     cam = create_cam2world_matrix(sample_camera_positions("cpu", "y", 0.7, 1.5, B), "y")
     P = R * R
     rng = {"u_strat": torch.rand(B, P, S), "eps_coarse": torch.randn(B, P, S), "u_fine": torch.rand(B, P, S),
            "eps_final": torch.randn(B, P, 2 * S)}
     params = {k: v.detach() for k, v in gen.siren.state_dict().items()}
-    ref = O.render(variant, params, fvol, glob, cam, R, 49.13, 0.25, 1.95, S, True, clamp, noise, white, last,
-                   rng["u_strat"], rng["eps_coarse"], rng["u_fine"], rng["eps_final"])
+    with torch.no_grad():
+        ref = O.render(variant, params, fvol, glob, cam, R, 49.13, 0.25, 1.95, S, True, clamp, noise, white, last,
+                       rng["u_strat"], rng["eps_coarse"], rng["u_fine"], rng["eps_final"])
     gen.to(dev)
     gen.set_device(dev)
-    gen.siren.precision = precision
     r = {k: v.to(dev) for k, v in rng.items()}
     r["fine_z"] = ref.aux["fine_z"].to(dev)
-    aux = {}
     z = (fvol.to(dev), glob.to(dev)) if has_glob else fvol.to(dev)
-    with torch.no_grad():
-        px, dp = gen(z, cam.to(dev), R, 49.13, 0.25, 1.95, S, True, clamp_mode=clamp, nerf_noise=noise, white_back=white,
-                     last_back=last, _rng=r, _aux=aux)
-    assert torch.equal(aux["coarse_points"].cpu(), ref.aux["coarse_points"])
-    assert torch.equal(aux["fine_points"].cpu(), ref.aux["fine_points"])
-    assert torch.equal(aux["sort_idx"].cpu().long(), ref.aux["sort_idx"])
-    assert scaled_err(aux["coarse_rgb_sigma"].cpu().numpy(), ref.aux["coarse_rgb_sigma"].numpy()) < TOL
-    assert scaled_err(aux["fine_rgb_sigma"].cpu().numpy(), ref.aux["fine_rgb_sigma"].numpy()) < TOL
-    assert (aux["inds"].cpu() == ref.aux["inds"]).float().mean() > 0.99
-    if P > 1:      # (a single ray has no rms to scale by)
-        assert scaled_err(px.cpu().numpy(), ref.pixels.numpy()) < 2 * TOL
-        assert scaled_err(dp.cpu().numpy(), ref.depth.numpy()) < 2 * TOL
-    else:
-        assert np.abs(px.cpu().numpy() - ref.pixels.numpy()).max() < 2e-4
+    out = {}
+    for prec in ((precision,) if isinstance(precision, str) else precision):
+        gen.siren.precision = prec
+        aux = {}
+        with torch.no_grad():
+            px, dp = gen(z, cam.to(dev), R, 49.13, 0.25, 1.95, S, True, clamp_mode=clamp, nerf_noise=noise, white_back=white,
+                         last_back=last, _rng=r, _aux=aux)
+        assert torch.equal(aux["coarse_points"].cpu(), ref.aux["coarse_points"]), prec
+        assert torch.equal(aux["fine_points"].cpu(), ref.aux["fine_points"]), prec
+        assert torch.equal(aux["sort_idx"].cpu().long(), ref.aux["sort_idx"]), prec
+        e_c = scaled_err(aux["coarse_rgb_sigma"].cpu().numpy(), ref.aux["coarse_rgb_sigma"].numpy())
+        e_f = scaled_err(aux["fine_rgb_sigma"].cpu().numpy(), ref.aux["fine_rgb_sigma"].numpy())
+        assert e_c < TOL and e_f < TOL, (prec, e_c, e_f)
+        same = (aux["inds"].cpu() == ref.aux["inds"]).float().mean().item()
+        assert same > 0.99, (prec, same)
+        if P > 1:      # (a single ray has no rms to scale by)
+            e_p, e_d = scaled_err(px.cpu().numpy(), ref.pixels.numpy()), scaled_err(dp.cpu().numpy(), ref.depth.numpy())
+            assert e_p < 2 * TOL and e_d < 2 * TOL, (prec, e_p, e_d)
+        else:
+            e_p = e_d = np.abs(px.cpu().numpy() - ref.pixels.numpy()).max()
+            assert e_p < 2e-4
+        out[prec] = dict(coarse=e_c, fine=e_f, inds_same=same, pixels=e_p, depth=e_d,
+                         survey_rs=survey_metric_pass(aux["coarse_rgb_sigma"].cpu().numpy(), ref.aux["coarse_rgb_sigma"].numpy()),
+                         survey_px=survey_metric_pass(px.cpu().numpy(), ref.pixels.numpy()))
+    return out
+
+
+def survey_metric_pass(a, b):
+    """Fraction of elements inside the gate SURVEY.md 8(d) wrote down, |a-b| <= 1e-4 * max(|b|, 1e-3), reported next to
+    scaled_err (whose floor is rms(b)): see DESIGN.md section 4 for why the gate of the tests is the latter."""
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.mean(np.abs(a - b) <= 1e-4 * np.maximum(np.abs(b), 1e-3)))
+
+
+def test_benchmarked_shape_matches_oracle(dev):
+    """The shape bench.py times -- SHORTSIREN_FG, hidden 256, 64^3 volume, 128x128 rays x (64 + 64) samples -- with TWO
+    images (the 8 XCD bands run over both, the fp16x3 kernel restages the FiLM vectors at the image switch, two 32-point tiles
+    per ray), against the CPU oracle on identical inputs and draws, both forward kernels: sample positions and merge order
+    bit-exact, rgb / sigma of both passes within 1e-4, image within 2e-4 (fine depths forced, as everywhere)."""
+    res = _oracle_case(dev, "SHORTSIREN_FG", B=2, R=128, S=64, V=64, H=256, Z=256, precision=("fp32", "fp16x3"), seed=11)
+    print("benchmarked shape:", res)
+
+
+def test_config2_shape_matches_oracle(dev):
+    """BASELINE config 2 as it is written: 64x64 rays x 24 samples, 64^3 volume, hidden 256, one image (the `short_fg_64x24`
+    fixture of the reference uses a 24^3 volume to stay small)."""
+    res = _oracle_case(dev, "SHORTSIREN_FG", B=1, R=64, S=24, V=64, H=256, Z=256, clamp="softplus", noise=0.5,
+                       precision=("fp32", "fp16x3"), seed=12)
+    print("config-2 shape:", res)
 
 
 @pytest.mark.parametrize("shape", [
@@ -454,6 +576,9 @@ def test_split_precision_wide_ragged(dev, H):
 
 def test_extreme_shapes_other_families(dev):
     _oracle_case(dev, "TALLSIREN_dRes", B=2, R=5, S=9, V=7, H=64, clamp="softplus", noise=0.4, last=True)
+    # the deepest residual chain at the width where the fp32 residual kernel spills registers (H = 256), ragged tiles
+    _oracle_case(dev, "TALLSIREN_dResLong", B=2, R=7, S=19, V=9, H=256, precision=("fp32", "fp16x3"), head_scale=10.0, seed=5)
+    _oracle_case(dev, "TALLSIREN_dResLong", B=1, R=5, S=9, V=7, H=128, clamp="softplus", noise=0.4, last=True, head_scale=10.0)
     _oracle_case(dev, "DOUBLESIREN_FG", B=1, R=4, S=17, V=4, H=128, white=False)
 
 
@@ -483,7 +608,8 @@ def test_precisions_agree_on_random_shapes(dev):
     from cnerf_amd.generators import ImplicitGenerator3d
     from oracle import render_oracle as O
     rs = np.random.RandomState(7)
-    fams = ["SHORTSIREN_FG", "DOUBLESIREN_FG", "TALLSIREN_FG", "SingleSIREN_dg", "SHORTSIREN_F", "SHORTSIREN_FRes", "TALLSIREN_dRes"]
+    fams = ["SHORTSIREN_FG", "DOUBLESIREN_FG", "TALLSIREN_FG", "SingleSIREN_dg", "SHORTSIREN_F", "SHORTSIREN_FRes", "TALLSIREN_dRes",
+            "TALLSIREN_dResLong"]
     for case in range(24):
         variant = fams[case % len(fams)]
         H = int(rs.choice([64, 128, 256]))

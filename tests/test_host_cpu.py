@@ -86,6 +86,21 @@ def test_camera_helpers():
     assert torch.allclose(fwd, -o / r.unsqueeze(-1), atol=1e-5)
 
 
+@pytest.mark.parametrize("name", GOLDEN_NAMES)
+def test_camera_helpers_match_reference(golden, name):
+    """sample_camera_positions + create_cam2world_matrix against the reference's own output: every fixture stores the
+    `cam2worlds` the reference produced right after np.random.seed(seed) (tests/golden/make_golden.py), so the same seed
+    must give the same matrices bit for bit (NumPy draw order theta, phi, r; float64 -> float32; columns -left, -up,
+    forward: volumetric_rendering.py:212-287)."""
+    from cnerf_amd.generators.volumetric_rendering import sample_camera_positions, create_cam2world_matrix
+    g = golden(name)
+    m = g.meta
+    np.random.seed(m["seed"])
+    o = sample_camera_positions("cpu", "y", cam_r_start=0.7, cam_r_end=1.5, n=m["B"])
+    cam = create_cam2world_matrix(o, "y", device="cpu").float()
+    assert np.array_equal(cam.numpy(), g["cam2worlds"])
+
+
 def test_unknown_variant_and_dropout():
     from cnerf_amd.generators import ImplicitGenerator3d
     with pytest.raises(AttributeError):

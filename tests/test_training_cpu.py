@@ -101,11 +101,25 @@ def test_on_disk_formats_round_trip(tmp_path):
     path = save_checkpoint(a, tmp_path / "checkpoints")
     assert path.endswith("41.tar")
     raw = torch.load(path, weights_only=True)
-    for k in ("step", "generator_state_dict", "optimizer_G_state_dict", "encoder_state_dict", "optimizer_E_state_dict",
-              "discriminator_state_dict", "optimizer_D_state_dict"):
-        assert k in raw
+    # exactly what the reference's Trainer.save_models writes with photo_loss and the discriminator on, depth_loss off
+    # (utils.py:473-501) -- its load_models reads scaler_state_dict and the four *_val / *_test histories unconditionally
+    ref_keys = {"step", "generator_state_dict", "optimizer_G_state_dict", "scaler_state_dict", "encoder_state_dict",
+                "optimizer_E_state_dict", "photometry_losses", "photometry_losses_val", "depth_losses_val",
+                "photometry_losses_test", "depth_losses_test", "discriminator_state_dict", "optimizer_D_state_dict",
+                "generator_losses", "discriminator_losses"}
+    assert set(raw) == ref_keys
+    torch.amp.GradScaler("cpu", enabled=True).load_state_dict(raw["scaler_state_dict"])     # the call utils.py:336 makes
     assert "siren.network.0.layer.weight" in raw["generator_state_dict"]
     b = make()
     load_checkpoint(b, path)
     assert b.generator.step == 41
     assert torch.equal(b.generator.siren.final_layer.bias, a.generator.siren.final_layer.bias)
+    assert b.losses == {"g": [0.5], "d": [1.25], "photo": [0.1]} and b.eval_losses["depth_losses_test"] == []
+    # a dictionary with the reference's key set (as its trainer would have written it, AMP scaler state included) loads too
+    ref_like = dict(raw)
+    ref_like["scaler_state_dict"] = {"scale": 1024.0, "growth_factor": 2.0, "backoff_factor": 0.5, "growth_interval": 2000, "_growth_tracker": 7}
+    ref_like["photometry_losses_val"] = [0.3, 0.2]
+    torch.save(ref_like, tmp_path / "ref_like.tar")
+    c = make()
+    load_checkpoint(c, tmp_path / "ref_like.tar")
+    assert c.eval_losses["photometry_losses_val"] == [0.3, 0.2] and c.generator.step == 41
