@@ -502,15 +502,31 @@ __global__ __launch_bounds__(256) void transpose_cl_kernel(const float* __restri
 // ---------------------------------------------------------------------------------------------------------------
 // unfused trilinear gather: 8 lanes per point, 4 channels (one 16-byte load per corner) per lane
 // ---------------------------------------------------------------------------------------------------------------
+// XCD-aware point ownership (as tile_range() of the fused kernels): blocks b and b + 8 share an XCD, so block class
+// b % 8 sweeps one contiguous eighth of the points -- a band of neighbouring rays, whose corner lines then stay in that
+// XCD's 4 MiB L2 instead of being fetched by all eight.  Placement only changes speed, never results.
+struct PointRange {
+    long long begin, end, stride;
+};
+__device__ __forceinline__ PointRange point_range(long long total) {
+    const int per_block = blockDim.x >> 3;             // 8 lanes per point
+    const int cls = blockIdx.x & 7, idx_in_cls = blockIdx.x >> 3;
+    const int blk_per_cls = (gridDim.x + 7 - cls) / 8;
+    PointRange r;
+    r.begin = total * cls / 8 + (long long)idx_in_cls * per_block + (threadIdx.x >> 3);
+    r.end = total * (cls + 1) / 8;
+    r.stride = (long long)blk_per_cls * per_block;
+    return r;
+}
+
 __global__ __launch_bounds__(256) void gather_kernel(GatherArgs a) {
     const int sub = threadIdx.x & 7;
-    const long long total = (long long)a.B * a.n_per_image;
-    const long long stride = (long long)gridDim.x * (blockDim.x >> 3);
-    for (long long pt = (long long)blockIdx.x * (blockDim.x >> 3) + (threadIdx.x >> 3); pt < total; pt += stride) {
+    const PointRange pr = point_range((long long)a.B * a.n_per_image);
+    for (long long pt = pr.begin; pt < pr.end; pt += pr.stride) {
         const long long b = pt / a.n_per_image;
         const float* p = a.points + pt * 3;
         Corner8 cr;
-        trilinear_corners(p[0], p[1], p[2], a.half_voxel, a.V, cr);
+        trilinear_corners(__builtin_nontemporal_load(p), __builtin_nontemporal_load(p + 1), __builtin_nontemporal_load(p + 2), a.half_voxel, a.V, cr);
         const float* vol = a.fvol + (size_t)b * a.V * a.V * a.V * 32 + 4 * sub;
         f32x4 q[8];
 #pragma unroll
@@ -520,7 +536,9 @@ __global__ __launch_bounds__(256) void gather_kernel(GatherArgs a) {
         for (int k = 0; k < 8; ++k)
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[e] = acc[e] + q[k][e] * cr.w[k];
-        *reinterpret_cast<f32x4*>(a.feat + pt * 32 + 4 * sub) = acc;
+        // streamed once: the 128 B per point written here (and the positions read above) must not evict the volume's corner
+        // lines from the XCD's L2, which every neighbouring ray re-reads
+        __builtin_nontemporal_store(acc, reinterpret_cast<f32x4*>(a.feat + pt * 32 + 4 * sub));
     }
 }
 
@@ -529,9 +547,8 @@ __global__ __launch_bounds__(256) void gather_kernel(GatherArgs a) {
 // FiLM family, whose MLP gradients are evaluated by library GEMMs on the host side (ops._pfilm_backward).
 __global__ __launch_bounds__(256) void scatter_kernel(GatherArgs a, const float* __restrict__ grad_feat, float* __restrict__ grad_fvol) {
     const int sub = threadIdx.x & 7;
-    const long long total = (long long)a.B * a.n_per_image;
-    const long long stride = (long long)gridDim.x * (blockDim.x >> 3);
-    for (long long pt = (long long)blockIdx.x * (blockDim.x >> 3) + (threadIdx.x >> 3); pt < total; pt += stride) {
+    const PointRange pr = point_range((long long)a.B * a.n_per_image);
+    for (long long pt = pr.begin; pt < pr.end; pt += pr.stride) {
         const long long b = pt / a.n_per_image;
         const float* p = a.points + pt * 3;
         Corner8 cr;
@@ -580,7 +597,7 @@ hipError_t launch_gather(const GatherArgs& a, hipStream_t stream) {
     const long long total = (long long)a.B * a.n_per_image;
     long long blocks = (total + 31) / 32;
     if (blocks > 256 * 16) blocks = 256 * 16;
-    if (blocks < 1) blocks = 1;
+    blocks = (blocks + 7) / 8 * 8;                    // every XCD class owns an eighth of the points
     hipLaunchKernelGGL(gather_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
@@ -589,7 +606,7 @@ hipError_t launch_scatter(const GatherArgs& a, const float* grad_feat, float* gr
     const long long total = (long long)a.B * a.n_per_image;
     long long blocks = (total + 31) / 32;
     if (blocks > 65536) blocks = 65536;
-    if (blocks < 1) blocks = 1;
+    blocks = (blocks + 7) / 8 * 8;
     hipLaunchKernelGGL(scatter_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a, grad_feat, grad_fvol);
     return hipGetLastError();
 }

@@ -30,16 +30,18 @@ def main():
     out = {"workload": "scripts/profile_workload.py 2 2 (batch 2, 128x128 rays x 64+64 samples, 64^3 volume, SHORTSIREN_FG hidden 256)",
            "method": "rocprofv3 --kernel-trace --pmc <one counter per pass>; FETCH_SIZE x2 (gfx950 wide reads), WRITE_SIZE x1; KB = 1024 B",
            "kernels": {}}
-    for prec in ("fp32", "fp16x3"):
+    for prec in ("fp32", "fp16x3", "unfused"):          # unfused: the gather / composite launches (CNERF_WORKLOAD=unfused)
         tabs = {c: collect(c, prec) for c in ("FETCH_SIZE", "WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum")}
         for name, fetch in tabs["FETCH_SIZE"].items():
             key = next((k for k in POINTS if name.startswith(k)), None)
             if key is None or name not in tabs["WRITE_SIZE"]:
                 continue
-            if key.startswith("void cnerf::field") and ((prec == "fp32") != ("field_tile" in key)):
+            if prec == "unfused" and key not in ("cnerf::gather_kernel", "cnerf::composite_kernel"):
+                continue                      # (that run's forward writes its sample points: not the benchmarked forward)
+            if prec != "unfused" and key.startswith("void cnerf::field") and ((prec == "fp32") != ("field_tile" in key)):
                 continue
-            if not key.startswith("void cnerf::field") and prec != "fp32":
-                continue                      # the per-ray and gather kernels do not depend on the precision: keep one copy
+            if prec == "fp16x3" and not key.startswith("void cnerf::field"):
+                continue                      # the per-ray kernels do not depend on the precision: keep one copy
             write = tabs["WRITE_SIZE"][name]
             hbm = (2 * fetch + write) * 1024.0
             e = {"fetch_size_kb": fetch, "write_size_kb": write, "hbm_bytes_per_launch": hbm, "points_per_launch": POINTS[key],

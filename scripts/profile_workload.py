@@ -2,7 +2,9 @@
 """Small fixed workload for rocprofv3 runs: a few ImplicitGenerator3d.forward calls at 128x128x64 (B images), then the
 unfused sample + composite pass of SURVEY.md 8(d) on the same samples (cnerf_gather_features over every coarse and fine
 point, cnerf_composite over the merged samples), nothing else on the GPU.
-Usage: rocprofv3 ... -- python3 scripts/profile_workload.py [B] [calls]      (CNERF_PRECISION=fp32|fp16x3)"""
+Usage: rocprofv3 ... -- python3 scripts/profile_workload.py [B] [calls]      (CNERF_PRECISION=fp32|fp16x3,
+CNERF_WORKLOAD=field: only the forward calls, no intermediates written -- what bench.py times;  unfused: one forward that
+writes its sample points, then the unfused gather + composite launches)"""
 import os
 import sys
 
@@ -23,11 +25,16 @@ gen.siren.precision = os.environ.get("CNERF_PRECISION", "fp32")
 fvol, glob = torch.randn(B, 32, 64, 64, 64, device=dev), torch.randn(B, 256, device=dev)
 cam = torch.eye(4, device=dev).unsqueeze(0).repeat(B, 1, 1)
 cam[:, 2, 3] = -1.0
+mode = os.environ.get("CNERF_WORKLOAD", "field")
 aux = {}
 with torch.no_grad():
-    for _ in range(calls):
+    for _ in range(calls if mode == "field" else 1):
         px, dp = gen((fvol, glob), cam, R, 49.134342641202636, 0.25, 1.95, S, True, clamp_mode="relu", nerf_noise=0.0,
-                     white_back=True, _aux=aux)
+                     white_back=True, **({} if mode == "field" else {"_aux": aux}))
+    if mode == "field":
+        torch.cuda.synchronize()
+        print("ok", float(px.mean()), float(dp.mean()), "points per field launch", B * R * R * S)
+        sys.exit(0)
     fcl = ops.channel_last(fvol)
     pts = torch.cat([aux["coarse_points"].reshape(B, -1, 3), aux["fine_points"].reshape(B, -1, 3)], 1).contiguous()
     allz = torch.cat([aux["fine_z"], aux["coarse_z"]], -1)
