@@ -477,6 +477,8 @@ class RenderFunction(torch.autograd.Function):
     def forward(ctx, net, o, rng, cam2world, freq, phase, n_vols, *rest):
         vols, params = rest[:n_vols], rest[n_vols:]
         levels = [channel_last(v.detach()) for v in vols]
+        # a volume that arrived channel-last (zero-copy above) gets its gradient back in the same memory format, again a view
+        ctx.vol_is_cl = [lv.data_ptr() == v.data_ptr() and not v.is_contiguous() for lv, v in zip(levels, vols)]
         fr = freq.detach() if freq is not None else None
         ph = phase.detach() if phase is not None else None
         need_grad = any(ctx.needs_input_grad)   # (grad mode is always off inside Function.forward)
@@ -501,7 +503,8 @@ class RenderFunction(torch.autograd.Function):
         g_levels, g_freq, g_phase, g_params = render_backward(ctx.net, ctx.o, levels, fr, ph, cam2world, ctx.rng, saved,
                                                               grad_pixels.contiguous(),
                                                               grad_depth.contiguous() if grad_depth is not None else None)
-        return (None, None, None, None, g_freq, g_phase, None, *[channel_first(g) for g in g_levels], *g_params)
+        g_vols = [g.permute(0, 4, 1, 2, 3) if cl else channel_first(g) for g, cl in zip(g_levels, ctx.vol_is_cl)]
+        return (None, None, None, None, g_freq, g_phase, None, *g_vols, *g_params)
 
 
 def render(net, fvol, freq, phase, cam2world, img_size, fov, ray_start, ray_end, num_steps, hierarchical, clamp_mode,

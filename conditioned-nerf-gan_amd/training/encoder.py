@@ -46,8 +46,10 @@ class _Up(nn.Module):
 
 
 class UNet3D(nn.Module):
-    def __init__(self, in_channels=4, out_channels=32, f_maps=32, num_levels=4, return_global=True, **_ignored):
+    def __init__(self, in_channels=4, out_channels=32, f_maps=32, num_levels=4, return_global=True,
+                 feature_volume_channels_last=True, **_ignored):
         super().__init__()
+        self.feature_volume_channels_last = feature_volume_channels_last
         widths = [f_maps * 2 ** k for k in range(num_levels)] if isinstance(f_maps, int) else list(f_maps)
         self.encoders = nn.ModuleList(_Down(in_channels if i == 0 else widths[i - 1], w, pool=i > 0) for i, w in enumerate(widths))
         rev = widths[::-1]
@@ -63,5 +65,19 @@ class UNet3D(nn.Module):
         glob = x.mean(dim=(2, 3, 4)) if self.return_global else None
         for dec, skip in zip(self.decoders, skips[1:]):
             x = dec(skip, x)
-        x = self.final_conv(x)
+        x = self._final(x)
         return (x, glob) if self.return_global else x
+
+    def _final(self, x):
+        """The final 1x1x1 convolution (unet3d.py:593), written channel-last: a 1x1x1 convolution is the GEMM
+        (B, V^3, f_maps) x (f_maps, out) -- evaluated in that orientation (rocBLAS reads the channel-first activations through
+        a transposed operand, no copy) its output IS the (B,V,V,V,C) layout the render kernels gather from, one 128-byte line
+        per trilinear corner.  The tensor handed on is the usual (B,C,V,V,V) view of it (torch.channels_last_3d strides), which
+        ops.channel_last() takes as it is: the hand-off to the render path costs no transpose kernel and no copy, forward or
+        backward.  Same parameters (`final_conv.weight/bias`), same values up to summation order."""
+        if not self.feature_volume_channels_last:
+            return self.final_conv(x)
+        B, C = x.shape[:2]
+        w = self.final_conv.weight.reshape(self.final_conv.out_channels, C)
+        y = torch.baddbmm(self.final_conv.bias.view(1, 1, -1), x.flatten(2).transpose(1, 2), w.t().unsqueeze(0).expand(B, -1, -1))
+        return y.view(B, *x.shape[2:], -1).permute(0, 4, 1, 2, 3)

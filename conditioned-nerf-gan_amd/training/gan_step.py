@@ -14,7 +14,7 @@ from torch.nn.parallel import DistributedDataParallel as DDP
 
 from ..generators import ImplicitGenerator3d
 from ..generators.volumetric_rendering import create_cam2world_matrix, sample_camera_positions
-from .discriminator import ProgressiveDiscriminator
+from . import discriminator as discriminators
 from .encoder import UNet3D
 
 
@@ -34,24 +34,36 @@ def default_metadata(img_size=128, num_steps=64, batch_size=8, batch_split=4, si
 
 
 class GanTrainer:
-    def __init__(self, metadata, device, ddp=False):
+    """metadata["discriminator"] names the class (ProgressiveDiscriminator, the reference's default, or CCSDiscriminator);
+    `modules` lets a caller hand in ready-made generator / encoder / discriminator modules (tests: a CPU stand-in generator
+    with the same call signature for the multi-rank gloo test; modules built from a fixture's parameters)."""
+
+    def __init__(self, metadata, device, ddp=False, modules=None):
         self.metadata, self.device, self.ddp = metadata, device, ddp
+        modules = modules or {}
         # MIOpen find mode for the 3-D convolutions of the encoder (and the discriminator): without it the immediate-mode
         # heuristic picks a naive weight-gradient solver for several Conv3d shapes -- encoder forward + backward of 2 voxel
         # grids 371 ms against 22 ms with the search (scripts/encoder_profile.py), i.e. 75 % of the whole GAN step.
         # Opt-in (train.py turns it on): the search itself takes minutes on a fresh machine, once per convolution shape.
         if metadata.get("miopen_find", False):
             torch.backends.cudnn.benchmark = True
-        self.generator = ImplicitGenerator3d(**metadata["generator"]).to(device)
-        self.generator.set_device(device)
-        # arithmetic of the forward render (both the no-grad D-step images and the G-step forward; the backward kernels are
-        # fp32 either way): "fp32" or the fp32-accurate split "fp16x3" (same parity gate, 2.7x faster)
-        self.generator.siren.precision = metadata.get("render_precision", "fp32")
-        self.encoder = UNet3D(**metadata["unet"]).to(device)
+        if "generator" in modules:
+            self.generator = modules["generator"].to(device)
+        else:
+            self.generator = ImplicitGenerator3d(**metadata["generator"]).to(device)
+            self.generator.set_device(device)
+            # arithmetic of the forward render (both the no-grad D-step images and the G-step forward): "fp32" or the
+            # fp32-accurate split "fp16x3" (same parity gate, 2.7x faster)
+            self.generator.siren.precision = metadata.get("render_precision", "fp32")
+        self.encoder = (modules["encoder"] if "encoder" in modules else UNet3D(**metadata["unet"])).to(device)
         if metadata.get("encoder_channels_last", False):     # NDHWC convolutions (MIOpen); off by default: measured below
             self.encoder = self.encoder.to(memory_format=torch.channels_last_3d)
-        self.discriminator = ProgressiveDiscriminator().to(device)
-        wrap = (lambda m, unused: DDP(m, device_ids=[device.index], find_unused_parameters=unused)) if ddp else (lambda m, unused: m)
+        if "discriminator" in modules:
+            self.discriminator = modules["discriminator"].to(device)
+        else:
+            self.discriminator = getattr(discriminators, metadata.get("discriminator", "ProgressiveDiscriminator"))().to(device)
+        ids = [device.index] if device.type == "cuda" else None          # (gloo / CPU ranks: no device ids)
+        wrap = (lambda m, unused: DDP(m, device_ids=ids, find_unused_parameters=unused)) if ddp else (lambda m, unused: m)
         self.generator_ddp = wrap(self.generator, True)
         self.encoder_ddp = wrap(self.encoder, False)
         self.discriminator_ddp = wrap(self.discriminator, True)
@@ -61,6 +73,12 @@ class GanTrainer:
         self.optimizer_D = adam(self.discriminator_ddp, metadata["disc_lr"])
         self.alpha = 1.0
         self.losses = {"d": [], "g": [], "photo": []}
+        self.last = {}          # diagnostics of the most recent step: loss terms and pre-clip gradient norms
+        self.render_rng = None  # test hook: callable(chunk_index, phase) -> dict of injected draws for that render
+
+    def _disc(self, imgs):
+        out = self.discriminator_ddp(imgs, self.alpha, **self.metadata)
+        return out[0] if isinstance(out, tuple) else out       # (CCSDiscriminator returns (prediction, None, None))
 
     # utils.py:610-618
     def set_alpha(self, step_last_upsample=0):
@@ -68,9 +86,10 @@ class GanTrainer:
         self.alpha = min(1.0, (step - step_last_upsample) / self.metadata["fade_steps"]) if self.metadata["fade_steps"] > 0 else 1.0
         self.metadata["nerf_noise"] = max(0.0, 1.0 - step / 5000.0)
 
-    def _render(self, voxels, cams):
+    def _render(self, voxels, cams, chunk=0, phase="g"):
         z = self.encoder_ddp(voxels)
-        return self.generator_ddp(z, cams, **self.metadata)
+        extra = {"_rng": self.render_rng(chunk, phase)} if self.render_rng is not None else {}
+        return self.generator_ddp(z, cams, **self.metadata, **extra)
 
     def _chunks(self, n):
         size = n // self.metadata["batch_split"]
@@ -87,19 +106,20 @@ class GanTrainer:
                 cams = create_cam2world_matrix(sample_camera_positions(self.device, "y", md["cam_r_start"], md["cam_r_end"], n), "y", self.device)
             else:
                 cams = sample["cam2world"].to(self.device)
-            fake = torch.cat([self._render(voxels[c], cams[c])[0] for c in self._chunks(n)], 0)
-        r_preds = self.discriminator_ddp(real, self.alpha, **md)
+            fake = torch.cat([self._render(voxels[c], cams[c], i, "d")[0] for i, c in enumerate(self._chunks(n))], 0)
+        r_preds = self._disc(real)
         penalty = 0.0
         if md["r1_lambda"] > 0:
             (grad_real,) = torch.autograd.grad(r_preds.sum(), real, create_graph=True)
             penalty = 0.5 * md["r1_lambda"] * grad_real.reshape(n, -1).norm(2, dim=1).pow(2).mean()
-        g_preds = self.discriminator_ddp(fake, self.alpha, **md)
+        g_preds = self._disc(fake)
         d_loss = F.softplus(g_preds).mean() + F.softplus(-r_preds).mean() + penalty
         self.optimizer_D.zero_grad()
         d_loss.backward()
-        torch.nn.utils.clip_grad_norm_(self.discriminator_ddp.parameters(), md["grad_clip"])
+        gn = torch.nn.utils.clip_grad_norm_(self.discriminator_ddp.parameters(), md["grad_clip"])
         self.optimizer_D.step()
         self.losses["d"].append(d_loss.item())
+        self.last.update(d_loss=d_loss.item(), r1_penalty=float(penalty), d_grad_norm=float(gn), fake_mean=float(fake.mean()))
 
     # utils.py:621-741
     def train_generator(self, sample):
@@ -114,22 +134,23 @@ class GanTrainer:
                 for m in (self.generator_ddp, self.encoder_ddp, self.discriminator_ddp):
                     ctx.enter_context(m.no_sync())
             with ctx:
-                gen_imgs, _ = self._render(voxels[c], cams[c])
+                gen_imgs, _ = self._render(voxels[c], cams[c], i, "g")
                 if md["enable_discriminator"]:
-                    loss_g = F.softplus(-self.discriminator_ddp(gen_imgs, self.alpha, **md)).mean()
+                    loss_g = F.softplus(-self._disc(gen_imgs)).mean()
                 else:
                     loss_g = gen_imgs.new_zeros(())
                 photo = F.mse_loss(gen_imgs, imgs[c]) if md["photo_loss"] else gen_imgs.new_zeros(())
                 (loss_g + photo).backward()
             g_acc += loss_g.item()
             p_acc += photo.item()
-        for model, opt in ((self.generator_ddp, self.optimizer_G), (self.encoder_ddp, self.optimizer_E)):
-            torch.nn.utils.clip_grad_norm_(model.parameters(), md.get("grad_clip", 0.3))
+        for name, model, opt in (("g", self.generator_ddp, self.optimizer_G), ("e", self.encoder_ddp, self.optimizer_E)):
+            self.last[name + "_grad_norm"] = float(torch.nn.utils.clip_grad_norm_(model.parameters(), md.get("grad_clip", 0.3)))
             opt.step()
             opt.zero_grad()
         self.optimizer_D.zero_grad()        # the G step also left gradients in the discriminator
         self.losses["g"].append(g_acc / len(chunks))
         self.losses["photo"].append(p_acc / len(chunks))
+        self.last.update(g_loss=g_acc / len(chunks), photo_loss=p_acc / len(chunks))
 
     def step(self, sample):
         self.set_alpha()

@@ -305,6 +305,144 @@ def build_coordconv():
     np.savez_compressed(os.path.join(HERE, "aux_coordconv.npz"), **out)
 
 
+def _param_stats(module):
+    """Per parameter: (sum, sum of absolute values, first three values) in float64 -- enough to tell that two modules built
+    under the same seed hold the same 12.9 M numbers without storing them."""
+    out = {}
+    for k, v in module.state_dict().items():
+        d = v.detach().double().flatten()
+        out[k] = np.array([d.sum().item(), d.abs().sum().item(), *d[:3].tolist(), *([0.0] * max(0, 3 - d.numel()))][:5])
+    return out
+
+
+def build_ccs():
+    """aux_ccs_discriminator.npz: discriminators/sgdiscriminators.py::CCSDiscriminator (importable; the progressive CoordConv
+    discriminator BASELINE.json calls "sgdiscriminator") under torch.manual_seed(0): parameter statistics and its outputs at
+    32 / 64 / 128 px for alpha 0, 0.5, 1 -- pins entry resolution, block list and fade-in of the restatement."""
+    sys.path.insert(0, REF)
+    from discriminators import sgdiscriminators as sgd
+    torch.manual_seed(0)
+    d = sgd.CCSDiscriminator()
+    d.eval()
+    out = {}
+    for k, v in _param_stats(d).items():
+        out["stat/" + k] = v
+    g = torch.Generator().manual_seed(1)
+    for res in (32, 64, 128):
+        x = torch.randn(1, 3, res, res, generator=g)
+        out[f"img_{res}"] = x.numpy()
+        for alpha in (0.0, 0.5, 1.0):
+            with torch.no_grad():
+                out[f"pred_{res}_{alpha}"] = d(x, alpha)[0].numpy()
+    np.savez_compressed(os.path.join(HERE, "aux_ccs_discriminator.npz"), **out)
+    print("aux_ccs_discriminator:", os.path.getsize(os.path.join(HERE, "aux_ccs_discriminator.npz")) / 1e6, "MB")
+
+
+def build_gan_step():
+    """aux_gan_step.npz: one D step and one G step of the GAN loop on the CPU with the reference's OWN modules -- generator
+    (generators.ImplicitGenerator3d SHORTSIREN_FG, hidden 64), voxel encoder (unet3d.UNet3D f_maps 8, 3 levels) and discriminator
+    (sgdiscriminators.CCSDiscriminator) -- fp32, 2 images of 16x16 rays x (8 + 8) samples.  The step logic (losses softplus(+-pred),
+    R1 penalty on the real images, gradient clipping, Adam(0, 0.9)) follows utils.py:621-842, which cannot be imported
+    (SURVEY.md F4), so it is spelled out here; everything it calls is the reference.  Stored: inputs, the generator's and the
+    encoder's parameters, the random draws of both renders, loss terms, pre-clip gradient norms, post-step parameter sums."""
+    sys.path.insert(0, REF)
+    from generators import generators as ref_gen, unet3d
+    from generators import volumetric_rendering as ref_vr
+    from discriminators import sgdiscriminators as sgd
+    R, S, B, V, H = 16, 8, 2, 8, 64
+    torch.manual_seed(0)
+    gen = ref_gen.ImplicitGenerator3d("SHORTSIREN_FG", z_dim=32, input_dim=32, output_dim=4, hidden_dim=H)
+    gen.set_device(torch.device("cpu"))
+    with torch.no_grad():                       # a head that yields visible structure (default init renders the background)
+        gen.siren.final_layer.weight[3] *= 20.0
+        gen.siren.final_layer.bias[3] += 0.5
+    enc = unet3d.UNet3D(in_channels=4, out_channels=32, f_maps=8, num_levels=3, final_sigmoid=False, is_segmentation=False,
+                        return_global=True)
+    torch.manual_seed(123)
+    disc = sgd.CCSDiscriminator()
+    gen.train(); enc.train(); disc.train()
+    gen.step = 1000
+    alpha, nerf_noise = min(1.0, 1000 / 2000), max(0.0, 1.0 - 1000 / 5000.0)          # utils.py:610-618
+    md = dict(img_size=R, num_steps=S, fov=FOV, ray_start=RAY_START, ray_end=RAY_END, white_back=True, last_back=False,
+              clamp_mode="relu", hierarchical_sample=True, nerf_noise=nerf_noise)
+    g = torch.Generator().manual_seed(5)
+    occ = (torch.rand(B, 1, V, V, V, generator=g) > 0.7).float()
+    vox = torch.cat([occ, torch.rand(B, 3, V, V, V, generator=g) * occ], 1)
+    imgs = torch.rand(B, 3, R, R, generator=g) * 2 - 1
+    np.random.seed(6)
+    cams_g = ref_vr.create_cam2world_matrix(ref_vr.sample_camera_positions(torch.device("cpu"), "y", 0.7, 1.5, B), "y", device=torch.device("cpu")).float()
+    out = {"voxel": vox.numpy(), "img": imgs.numpy(), "cam2world": cams_g.numpy(), "alpha": np.float32(alpha), "nerf_noise": np.float32(nerf_noise)}
+    for k, v in gen.state_dict().items():
+        out["gen/" + k] = v.numpy().copy()
+    for k, v in enc.state_dict().items():
+        out["enc/" + k] = v.numpy().copy()
+    for k, v in _param_stats(disc).items():
+        out["dstat/" + k] = v
+    opt = lambda m, lr: torch.optim.Adam(m.parameters(), lr=lr, betas=(0.0, 0.9), weight_decay=0)
+    opt_g, opt_e, opt_d = opt(gen, 5e-5), opt(enc, 5e-5), opt(disc, 2e-4)
+
+    o_rand, o_randn = torch.rand, torch.randn
+    draws = []
+
+    def capture():
+        rec = {"rand": [], "randn": []}
+        torch.rand = lambda *a, **k: rec["rand"].append(o_rand(*a, **k)) or rec["rand"][-1]
+        torch.randn = lambda *a, **k: rec["randn"].append(o_randn(*a, **k)) or rec["randn"][-1]
+        return rec
+
+    def release(rec, tag):
+        torch.rand, torch.randn = o_rand, o_randn
+        P = R * R
+        out[tag + "/u_strat"] = rec["rand"][0].numpy().reshape(B, P, S)
+        out[tag + "/u_fine"] = rec["rand"][1].numpy().reshape(B, P, S)
+        out[tag + "/eps_coarse"] = rec["randn"][0].numpy().reshape(B, P, S)
+        out[tag + "/eps_final"] = rec["randn"][1].numpy().reshape(B, P, 2 * S)
+
+    # ---- discriminator step (utils.py:743-842) ----
+    np.random.seed(7)
+    cams_d = ref_vr.create_cam2world_matrix(ref_vr.sample_camera_positions(torch.device("cpu"), "y", 0.7, 1.5, B), "y", device=torch.device("cpu")).float()
+    out["cam2world_d"] = cams_d.numpy()
+    with torch.no_grad():
+        rec = capture()
+        try:
+            fake, _ = gen(enc(vox), cams_d, **md)
+        finally:
+            release(rec, "d")
+    real = imgs.clone().requires_grad_(True)
+    r_preds = disc(real, alpha)[0]
+    (grad_real,) = torch.autograd.grad(r_preds.sum(), real, create_graph=True)
+    penalty = 0.5 * 10 * (grad_real.view(B, -1).norm(2, dim=1) ** 2).mean()
+    g_preds = disc(fake, alpha)[0]
+    d_loss = F.softplus(g_preds).mean() + F.softplus(-r_preds).mean() + penalty
+    opt_d.zero_grad()
+    d_loss.backward()
+    d_norm = torch.nn.utils.clip_grad_norm_(disc.parameters(), 1)
+    opt_d.step()
+    out.update(d_loss=np.float64(d_loss.item()), r1_penalty=np.float64(penalty.item()), d_grad_norm=np.float64(float(d_norm)),
+               fake_mean=np.float64(fake.mean().item()), fake=fake.numpy())
+    # ---- generator step (utils.py:621-741), batch_split 1 ----
+    rec = capture()
+    try:
+        gen_imgs, _ = gen(enc(vox), cams_g, **md)
+    finally:
+        release(rec, "g")
+    loss_g = F.softplus(-disc(gen_imgs, alpha)[0]).mean()
+    photo = ((imgs - gen_imgs) ** 2).mean()
+    (loss_g + photo).backward()
+    g_norm = torch.nn.utils.clip_grad_norm_(gen.parameters(), 1)
+    opt_g.step()
+    e_norm = torch.nn.utils.clip_grad_norm_(enc.parameters(), 1)
+    opt_e.step()
+    out.update(g_loss=np.float64(loss_g.item()), photo_loss=np.float64(photo.item()), g_grad_norm=np.float64(float(g_norm)),
+               e_grad_norm=np.float64(float(e_norm)), gen_imgs=gen_imgs.detach().numpy())
+    for k, v in gen.state_dict().items():
+        out["gen_after_sum/" + k] = np.float64(v.double().sum().item())
+    out["enc_after_sum/final_conv.weight"] = np.float64(enc.final_conv.weight.double().sum().item())
+    np.savez_compressed(os.path.join(HERE, "aux_gan_step.npz"), **out)
+    print("aux_gan_step:", os.path.getsize(os.path.join(HERE, "aux_gan_step.npz")) / 1e6, "MB;",
+          {k: float(out[k]) for k in ("d_loss", "r1_penalty", "d_grad_norm", "g_loss", "photo_loss", "g_grad_norm", "e_grad_norm", "fake_mean")})
+
+
 if __name__ == "__main__":
     names = sys.argv[1:] or list(FIXTURES)
     for n in names:
@@ -312,5 +450,9 @@ if __name__ == "__main__":
             build_unet3d()
         elif n == "coordconv":
             build_coordconv()
+        elif n == "ccs":
+            build_ccs()
+        elif n == "gan_step":
+            build_gan_step()
         else:
             build(n)

@@ -42,3 +42,91 @@ def test_gan_step_ddp_one_rank_rccl():
         _run(ddp=True)
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fp16x3"])
+def test_gan_step_matches_reference_modules(precision):
+    """One D step and one G step through the HIP render path (forward and backward) against tests/golden/aux_gan_step.npz: the
+    same step run on the CPU with the reference's own generator, UNet3D and CCSDiscriminator modules, fp32 (step logic of
+    utils.py:621-842 spelled out in tests/golden/make_golden.py::build_gan_step -- that file cannot be imported).  Same
+    parameters (generator / encoder from the fixture, discriminator rebuilt under its seed and checked), same voxels, images,
+    cameras and random draws; the renders run free (nothing forced).  Pinned: D loss, R1 penalty, G loss, photometric loss,
+    the pre-clip gradient norms of all three networks, the post-step parameters of the generator."""
+    import numpy as np
+    from conftest import GOLDEN_DIR
+    import cnerf_amd
+    from cnerf_amd.generators import ImplicitGenerator3d
+    from cnerf_amd.training import GanTrainer, default_metadata, UNet3D, CCSDiscriminator
+    d = np.load(os.path.join(GOLDEN_DIR, "aux_gan_step.npz"))
+    dev = torch.device("cuda:0")
+    T = lambda k: torch.from_numpy(np.asarray(d[k]))
+    gen = ImplicitGenerator3d("SHORTSIREN_FG", 32, 32, 4, 64)
+    gen.load_state_dict({k[len("gen/"):]: T(k) for k in d.files if k.startswith("gen/")}, strict=True)
+    enc = UNet3D(in_channels=4, out_channels=32, f_maps=8, num_levels=3, return_global=True)
+    enc.load_state_dict({k[len("enc/"):]: T(k) for k in d.files if k.startswith("enc/")}, strict=True)
+    torch.manual_seed(123)
+    disc = CCSDiscriminator()
+    for k, v in disc.state_dict().items():
+        f = v.double().flatten()
+        mine = np.array([f.sum().item(), f.abs().sum().item(), *f[:3].tolist(), *([0.0] * max(0, 3 - f.numel()))][:5])
+        assert np.allclose(mine, d["dstat/" + k], rtol=1e-12, atol=1e-12), k
+    md = default_metadata(img_size=16, num_steps=8, batch_size=2, batch_split=1, hidden_dim=64)
+    md["discriminator"] = "CCSDiscriminator"
+    tr = GanTrainer(md, dev, modules={"generator": gen, "encoder": enc, "discriminator": disc})
+    tr.generator.set_device(dev)
+    tr.generator.siren.precision = precision
+    tr.generator.train(); tr.encoder.train(); tr.discriminator.train()
+    tr.generator.step = 1000
+    tr.set_alpha()
+    assert abs(tr.alpha - float(d["alpha"])) < 1e-7 and abs(md["nerf_noise"] - float(d["nerf_noise"])) < 1e-6
+    tr.render_rng = lambda chunk, phase: {k: T(f"{phase}/{k}").to(dev) for k in ("u_strat", "u_fine", "eps_coarse", "eps_final")}
+    sample = {"voxel": T("voxel"), "img": T("img"), "cam2world": T("cam2world")}
+    np.random.seed(7)                                     # the D step samples its cameras from NumPy (bit-exact helper)
+    tr.train_discriminator(sample)
+    tr.train_generator(sample)
+    got = dict(tr.last)
+    print(precision, {k: (got[k], float(d[k])) for k in ("d_loss", "r1_penalty", "d_grad_norm", "fake_mean", "g_loss", "photo_loss",
+                                                          "g_grad_norm", "e_grad_norm")})
+    rel = lambda k: abs(got[k] - float(d[k])) / max(abs(float(d[k])), 1e-6)
+    for k in ("d_loss", "r1_penalty", "g_loss", "photo_loss"):
+        assert rel(k) < 2e-3, (k, got[k], float(d[k]))
+    assert abs(got["fake_mean"] - float(d["fake_mean"])) < 2e-3
+    for k in ("d_grad_norm", "g_grad_norm", "e_grad_norm"):
+        assert rel(k) < 2e-2, (k, got[k], float(d[k]))
+    # Adam's first step moves every parameter by ~lr * sign(gradient): sums after the step pin the signs of the gradients
+    for k, v in tr.generator.state_dict().items():
+        ref = float(d["gen_after_sum/" + k])
+        assert abs(v.double().sum().item() - ref) < 2e-3 * max(1.0, abs(ref)) + 5e-5 * v.numel() * 0.02, k
+
+
+def test_encoder_hands_its_volume_over_channel_last():
+    """the encoder's final 1x1x1 convolution writes the feature volume channel-last, the render kernels take it
+    without a transpose or a copy (forward), and d(loss)/d(volume) goes back in the same layout (backward).  Same image and
+    same encoder gradients as with the channel-first output + transpose kernels."""
+    import cnerf_amd
+    from cnerf_amd import ops
+    from cnerf_amd.generators import ImplicitGenerator3d
+    from cnerf_amd.training import UNet3D
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    enc = UNet3D(in_channels=4, out_channels=32, f_maps=8, num_levels=2, return_global=True).to(dev)
+    gen = ImplicitGenerator3d("SHORTSIREN_FG", 16, 32, 4, 64).to(dev)
+    gen.set_device(dev)
+    gen.train()
+    vox = torch.rand(2, 4, 8, 8, 8, device=dev)
+    cam = torch.eye(4, device=dev).unsqueeze(0).repeat(2, 1, 1).contiguous()
+    cam[:, 2, 3] = -1.0
+    rng = {"u_strat": torch.rand(2, 36, 8, device=dev), "u_fine": torch.rand(2, 36, 8, device=dev)}
+    outs = []
+    for cl in (True, False):
+        enc.feature_volume_channels_last = cl
+        enc.zero_grad()
+        fv, glob = enc(vox)
+        assert (ops.channel_last(fv).data_ptr() == fv.data_ptr()) == cl          # zero-copy exactly when written channel-last
+        px, dp = gen((fv, glob), cam, 6, 49.13, 0.25, 1.95, 8, True, clamp_mode="relu", nerf_noise=0.0, _rng=rng)
+        (px.square().mean() + dp.mean()).backward()
+        outs.append((px.detach().clone(), enc.final_conv.weight.grad.clone(), enc.encoders[0].basic_module.SingleConv1.conv.weight.grad.clone()))
+    (pa, ga, ea), (pb, gb, eb) = outs
+    assert (pa - pb).abs().max().item() < 1e-5
+    assert (ga - gb).abs().max().item() < 1e-4 * gb.abs().max().item() + 1e-7
+    assert (ea - eb).abs().max().item() < 1e-3 * eb.abs().max().item() + 1e-7

@@ -123,3 +123,30 @@ def test_on_disk_formats_round_trip(tmp_path):
     c = make()
     load_checkpoint(c, tmp_path / "ref_like.tar")
     assert c.eval_losses["photometry_losses_val"] == [0.3, 0.2] and c.generator.step == 41
+
+
+def test_ccs_discriminator_matches_reference():
+    """CCSDiscriminator against discriminators/sgdiscriminators.py of the reference (tests/golden/make_golden.py ccs): the same
+    torch seed gives the same 12.9 M parameters (construction order and initialisers are the reference's), and the outputs
+    at 32 / 64 / 128 px agree for alpha 0, 0.5 and 1 -- entry block per resolution, strided residual blocks, fade-in of the
+    half-resolution image after the first block (skipped at alpha = 1), 2x2 final convolution."""
+    from cnerf_amd.training import CCSDiscriminator
+    d = np.load(os.path.join(GOLDEN_DIR, "aux_ccs_discriminator.npz"))
+    torch.manual_seed(0)
+    net = CCSDiscriminator()
+    net.eval()
+    sd = net.state_dict()
+    stats = {k[len("stat/"):]: d[k] for k in d.files if k.startswith("stat/")}
+    assert set(sd) == set(stats)
+    assert sum(p.numel() for p in net.parameters()) == 12_879_217
+    for k, v in sd.items():
+        f = v.double().flatten()
+        mine = np.array([f.sum().item(), f.abs().sum().item(), *f[:3].tolist(), *([0.0] * max(0, 3 - f.numel()))][:5])
+        assert np.allclose(mine, stats[k], rtol=1e-12, atol=1e-12), k
+    for res in (32, 64, 128):
+        x = torch.from_numpy(d[f"img_{res}"])
+        for alpha in (0.0, 0.5, 1.0):
+            with torch.no_grad():
+                pred, a, b = net(x, alpha)
+            assert a is None and b is None
+            assert np.abs(pred.numpy() - d[f"pred_{res}_{alpha}"]).max() < 1e-5, (res, alpha)
