@@ -119,7 +119,7 @@ class GanTrainer:
         gn = torch.nn.utils.clip_grad_norm_(self.discriminator_ddp.parameters(), md["grad_clip"])
         self.optimizer_D.step()
         self.losses["d"].append(d_loss.item())
-        self.last.update(d_loss=d_loss.item(), r1_penalty=float(penalty), d_grad_norm=float(gn), fake_mean=float(fake.mean()))
+        self.last.update(d_loss=d_loss.item(), r1_penalty=float(penalty.detach()) if torch.is_tensor(penalty) else float(penalty), d_grad_norm=float(gn), fake_mean=float(fake.mean()))
 
     # utils.py:621-741
     def train_generator(self, sample):
@@ -151,6 +151,28 @@ class GanTrainer:
         self.losses["g"].append(g_acc / len(chunks))
         self.losses["photo"].append(p_acc / len(chunks))
         self.last.update(g_loss=g_acc / len(chunks), photo_loss=p_acc / len(chunks))
+
+    def warm_convolutions(self, sample):
+        """One throw-away forward + backward of the encoder and the discriminator on the RAW modules (no DDP collective, no
+        optimizer step, gradients discarded), with the shapes a training step uses.  With MIOpen find mode on, this is where
+        the convolution-kernel search happens (minutes on a fresh machine).  train.py runs it on rank 0 first and on the other
+        ranks after a barrier: MIOpen keeps its find results in the user database (MIOPEN_USER_DB_PATH, one directory per
+        node), so ranks 1..N-1 read rank 0's results instead of each repeating the search concurrently."""
+        md = self.metadata
+        n = sample["img"].shape[0]
+        c = self._chunks(n)[0]
+        vox = sample["voxel"][c].to(self.device)
+        fv, glob = self.encoder(vox)
+        (fv.square().mean() + glob.square().mean()).backward()
+        real = sample["img"].to(self.device).requires_grad_(True)
+        out = self.discriminator(real, self.alpha, **md)
+        pred = out[0] if isinstance(out, tuple) else out
+        (grad_real,) = torch.autograd.grad(pred.sum(), real, create_graph=True)
+        (F.softplus(-pred).mean() + grad_real.square().mean()).backward()
+        out = self.discriminator(real.detach()[c], self.alpha, **md)          # the G-step chunk size
+        (out[0] if isinstance(out, tuple) else out).mean().backward()
+        for m in (self.encoder, self.discriminator):
+            m.zero_grad(set_to_none=True)
 
     def step(self, sample):
         self.set_alpha()

@@ -88,11 +88,14 @@ def test_gan_step_matches_reference_modules(precision):
     print(precision, {k: (got[k], float(d[k])) for k in ("d_loss", "r1_penalty", "d_grad_norm", "fake_mean", "g_loss", "photo_loss",
                                                           "g_grad_norm", "e_grad_norm")})
     rel = lambda k: abs(got[k] - float(d[k])) / max(abs(float(d[k])), 1e-6)
-    for k in ("d_loss", "r1_penalty", "g_loss", "photo_loss"):
-        assert rel(k) < 2e-3, (k, got[k], float(d[k]))
-    assert abs(got["fake_mean"] - float(d["fake_mean"])) < 2e-3
+    # measured on an MI355X (both precisions): d_loss 2e-6, r1 2e-7, g_loss 1e-5, photo 2.2e-4 (free-running renders: the
+    # resampled depths differ at the 1e-5 level), gradient norms 4e-5 .. 3.1e-3
+    for k in ("d_loss", "r1_penalty", "g_loss"):
+        assert rel(k) < 1e-4, (k, got[k], float(d[k]))
+    assert rel("photo_loss") < 1e-3
+    assert abs(got["fake_mean"] - float(d["fake_mean"])) < 1e-4
     for k in ("d_grad_norm", "g_grad_norm", "e_grad_norm"):
-        assert rel(k) < 2e-2, (k, got[k], float(d[k]))
+        assert rel(k) < 1e-2, (k, got[k], float(d[k]))
     # Adam's first step moves every parameter by ~lr * sign(gradient): sums after the step pin the signs of the gradients
     for k, v in tr.generator.state_dict().items():
         ref = float(d["gen_after_sum/" + k])

@@ -67,6 +67,21 @@ def main():
         if rank == 0:
             print(f"resumed from {args.resume} at step {ck['step']}", flush=True)
     gen = torch.Generator().manual_seed(1000 + rank)
+    if md["miopen_find"]:
+        # MIOpen's kernel search runs once per node: rank 0 first, the others after it (they find its results in the shared user
+        # database instead of searching for ~7 minutes each, all at once)
+        os.environ.setdefault("MIOPEN_USER_DB_PATH", os.path.join(os.path.expanduser("~"), ".config", "miopen"))
+        warm = synthetic_sample(args.batch, args.img_size, args.voxel_res, dev, torch.Generator().manual_seed(1))
+        if rank == 0:
+            t0 = time.perf_counter()
+            trainer.warm_convolutions(warm)
+            torch.cuda.synchronize()
+            print(f"convolution kernels selected in {time.perf_counter() - t0:.1f} s (MIOpen find mode, results in {os.environ['MIOPEN_USER_DB_PATH']})", flush=True)
+        if world > 1:
+            dist.barrier()
+            if rank != 0:
+                trainer.warm_convolutions(warm)
+            dist.barrier()
     import threading
     first_done = threading.Event()
 
