@@ -8,7 +8,7 @@ LIB_PATH = os.path.join(HERE, "libcnerf_hip.so")
 
 MAX_LAYERS = 16
 MAX_LEVELS = 4
-ABI_VERSION = 3
+ABI_VERSION = 4
 F_HIERARCHICAL, F_WHITE_BACK, F_LAST_BACK, F_SOFTPLUS, F_SIGMOID_RGB, F_INPUT_XYZ = 1, 2, 4, 8, 16, 32
 PREC_FP32, PREC_FP16X3 = 0, 2
 PREC_CODE = {"fp32": PREC_FP32, "fp16x3": PREC_FP16X3}
@@ -73,7 +73,13 @@ PROTOTYPES = {
     "cnerf_merge_composite_backward": (C.c_int, [C.POINTER(Cfg)] + [C.c_void_p] * 10),
     "cnerf_field_backward": (C.c_int, [C.POINTER(Cfg), C.c_int32, C.c_int32, C.c_int32, C.POINTER(Volumes)] + [C.c_void_p] * 14 +
                              [C.POINTER(Volumes), C.c_void_p]),
+    "cnerf_weight_grad16": (C.c_int, [C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 6),
+    "cnerf_backward16_bytes": (C.c_int, [C.POINTER(Cfg), C.POINTER(C.c_size_t)]),
+    "cnerf_pack_field_chain16": (C.c_int, [C.POINTER(Cfg), C.POINTER(FieldParams), C.c_void_p, C.c_void_p]),
+    "cnerf_field_backward16": (C.c_int, [C.POINTER(Cfg), C.c_uint32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(Volumes)] +
+                               [C.c_void_p] * 16 + [C.POINTER(Volumes), C.c_void_p]),
 }
+B16_STORE, B16_DRY, B16_CHAIN = 1, 2, 4
 
 _lib = None
 

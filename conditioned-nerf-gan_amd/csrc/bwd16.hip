@@ -1,0 +1,623 @@
+// Half-precision backward of the field network for gfx950 (the counterpart of the reference's fp16 autocast training,
+// utils.py:643-711: activations and their gradients in fp16, sums in fp32).  Two kernels:
+//
+//   weight_grad16_kernel   dW[b] += G[b]^T X[b], colsum[b] += sum G[b]   per image b, G = d loss / d (sine argument) of one
+//                          matrix, X = that matrix' input, both fp16 in the TB16 layout (bwd16.hpp), v_mfma_f32_32x32x16_f16
+//                          with the point dimension as k, fp32 accumulators.
+//   (chain16, further down) the gradient chain g_{l-1} = W_l^T (g_l cos(arg_l) freq_l) on the same instruction.
+//
+// Why fp16 here: on gfx950 the fp32 MFMA runs at the vector rate (1/16 of the fp16 rate), which made the two gradient GEMM
+// families 60 % of a training step of the render path; their operands are bounded (sines, cosines) or scaled per layer by a
+// power of two, every sum is fp32, and the quantity they feed (a weight gradient over ~1e6 points) carries the operand
+// rounding (2^-11 relative, zero mean) at the 4e-4 level -- inside the gradient gate of the tests (2e-3 of the reference's
+// autograd).  The exact fp32 path (field_kernel.hip / grad_kernels.hip) stays available: ops.py `backward_precision`.
+#include "bwd16.hpp"
+#include "cnerf_dev.hpp"
+#include "cnerf_kernels.hpp"
+#include "field_common.hpp"
+
+namespace cnerf {
+
+typedef __fp16 hv4 __attribute__((__vector_size__(8)));
+
+// ds_read_b64_tr_b16: per group of 16 lanes a block of 4 rows x 16 columns of 16-bit elements, delivered column-major: lane i
+// of the group receives column i of the 4 rows.  Lane 4q + p of the group supplies the address of row q, columns 4p .. 4p+3.
+// (Layout and lane map verified on hardware by scripts/ubench/tr16_probe.hip.)
+__device__ __forceinline__ u32x2_ lds_tr16(const char* p) {
+    const hv4 v = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) hv4*)p);
+    return __builtin_bit_cast(u32x2_, v);
+}
+__device__ __forceinline__ f16x8 frag8(u32x2_ lo, u32x2_ hi) {
+    const u32x4 v = {lo[0], lo[1], hi[0], hi[1]};
+    return __builtin_bit_cast(f16x8, v);
+}
+
+// acc += lo(x) + hi(x) for a packed fp16 pair, fp32 accumulate
+__device__ __forceinline__ void dot2_ones(float& acc, uint32_t x) {
+    asm volatile("v_dot2_f32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(x), "v"(0x3c003c00u));
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// weight gradients
+// ---------------------------------------------------------------------------------------------------------------
+struct WeightGrad16Args {
+    const _Float16* G;        // TB16 (tiles, g_ct, 32, 32): the first NOC channel tiles are this call's output rows
+    const _Float16* X;        // TB16 (tiles, x_ct, 32, 32): channel tiles [x_t0, x_t0 + NJ) are this call's columns
+    float* dW;                // (cnt, n_rows, ld) accumulated into, true units
+    float* colsum;            // (cnt, n_rows) accumulated into (null: skipped)
+    const float* inv_scale;   // device scalar: G holds scale * g; null: 1
+    long long tiles_per_image;
+    int cnt, g_ct, x_ct, x_t0, ld, n_rows, blocks_per_image;
+};
+
+// One block = NOC waves; wave w owns output rows [32 w, 32 w + 32) x NJ column tiles (NJ * 16 accumulator registers).  A stage
+// = one 32-point tile: its G block (NOC x 2 KiB) and X block (NJ x 2 KiB) are copied into LDS by linear LDS-DMA (1 KiB per
+// wave instruction), double-buffered, one barrier per stage.  Per 16-point k-chunk a wave reads its A fragment (8 points of
+// its output channel per lane) and the NJ B fragments with two transposed reads each and issues NJ MFMAs.
+template <int NOC, int NJ>
+__global__ __launch_bounds__(64 * NOC) void weight_grad16_kernel(WeightGrad16Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem16[];
+    constexpr int STAGE = (NOC + NJ) * 2048;                 // bytes
+    constexpr int PIECES = (NOC + NJ) * 2;                   // 1-KiB pieces per stage
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int b = blockIdx.x / a.blocks_per_image, part = blockIdx.x - b * a.blocks_per_image;
+    const long long t_begin = a.tiles_per_image * part / a.blocks_per_image, t_end = a.tiles_per_image * (part + 1) / a.blocks_per_image;
+    const long long tile0 = (long long)b * a.tiles_per_image;
+    const char* Gb = reinterpret_cast<const char*>(a.G);
+    const char* Xb = reinterpret_cast<const char*>(a.X);
+
+    auto dma_stage = [&](long long t, int buf) {
+        char* dst = smem16 + buf * STAGE;
+        const char* gsrc = Gb + (size_t)(tile0 + t) * a.g_ct * 2048;
+        const char* xsrc = Xb + ((size_t)(tile0 + t) * a.x_ct + a.x_t0) * 2048;
+#pragma unroll
+        for (int i = 0; i < (PIECES + NOC - 1) / NOC; ++i) {
+            const int p = wave_u + i * NOC;                  // wave-uniform
+            if (p < PIECES) {
+                const char* src = (p < 2 * NOC ? gsrc + p * 1024 : xsrc + (p - 2 * NOC) * 1024) + lane * 16;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(dst + p * 1024), 16, 0, 0);
+            }
+        }
+    };
+
+    f32x16 acc[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+    float cs = 0.0f;
+    // the lane's address inside a 2-KiB block for k-chunk 0, read 0: row (point) 8h + q, columns 16 grp + 4p
+    const int grp = (lane >> 4) & 1, h = lane >> 5, q = (lane & 15) >> 2, p4 = lane & 3;
+    const int lane_off = (8 * h + q) * 64 + (16 * grp + 4 * p4) * 2;
+
+    if (t_begin < t_end) dma_stage(t_begin, 0);
+    int cur = 0;
+    for (long long t = t_begin; t < t_end; ++t) {
+        __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): this wave's pieces of stage t have landed
+        __syncthreads();                                     // ... and everybody else's; the other buffer is free
+        if (t + 1 < t_end) dma_stage(t + 1, cur ^ 1);
+        const char* gs = smem16 + cur * STAGE + wave * 2048 + lane_off;
+        const char* xs = smem16 + cur * STAGE + NOC * 2048 + lane_off;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {                        // two k-chunks of 16 points
+            const u32x2_ a0 = lds_tr16(gs + c * 1024), a1 = lds_tr16(gs + c * 1024 + 256);
+            const f16x8 A = frag8(a0, a1);
+            u32x2_ b0[NJ], b1[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                b0[j] = lds_tr16(xs + j * 2048 + c * 1024);
+                b1[j] = lds_tr16(xs + j * 2048 + c * 1024 + 256);
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, frag8(b0[j], b1[j]), acc[j], 0, 0, 0);
+            // column sums of G: sum of the lane's 8 points of its channel, fp32 (v_dot2_f32_f16 against (1, 1); written as asm
+            // because hipcc 7.2 folds the builtin's second dword of a transposed-read pair onto the first: v_dot2c ... v8, v8)
+            dot2_ones(cs, a0[0]);
+            dot2_ones(cs, a0[1]);
+            dot2_ones(cs, a1[0]);
+            dot2_ones(cs, a1[1]);
+        }
+        cur ^= 1;
+    }
+    // D[i][j]: lane (c = lane & 31, h), register r holds row (r & 3) + 8 (r >> 2) + 4 h, column c of the 32 x 32 tile
+    const float inv = a.inv_scale ? *a.inv_scale : 1.0f;
+    const int col = lane & 31;
+    float* dWb = a.dW + (size_t)b * a.n_rows * a.ld + 32 * a.x_t0;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (row < a.n_rows) atomicAdd(dWb + (size_t)row * a.ld + 32 * j + col, acc[j][r] * inv);
+        }
+    if (a.colsum) {
+        const float tot = cs + __shfl_xor(cs, 32, WAVE);     // the two lane halves hold the two halves of the points
+        const int row = 32 * wave + col;
+        if (h == 0 && row < a.n_rows) atomicAdd(a.colsum + (size_t)b * a.n_rows + row, tot * inv);
+    }
+}
+
+template <int NOC, int NJ>
+static hipError_t launch_wg16_inst(const WeightGrad16Args& a, hipStream_t stream) {
+    const int lds_bytes = 2 * (NOC + NJ) * 2048;
+    if (hipError_t e = hipFuncSetAttribute((const void*)weight_grad16_kernel<NOC, NJ>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)) return e;
+    hipLaunchKernelGGL((weight_grad16_kernel<NOC, NJ>), dim3((unsigned)(a.cnt * a.blocks_per_image)), dim3(64 * NOC), lds_bytes, stream, a);
+    return hipGetLastError();
+}
+
+template <int NOC>
+static hipError_t launch_wg16_noc(const WeightGrad16Args& a, int nj, hipStream_t stream) {
+    switch (nj) {
+        case 1: return launch_wg16_inst<NOC, 1>(a, stream);
+        case 2: return launch_wg16_inst<NOC, 2>(a, stream);
+        case 4: return launch_wg16_inst<NOC, 4>(a, stream);
+        case 8: return launch_wg16_inst<NOC, 8>(a, stream);
+    }
+    return hipErrorInvalidValue;
+}
+
+// dW (cnt, n_rows, K) += G^T X over the tiles of each image; K = 32 * x_ct columns in runs of 8 / 4 / 2 / 1 channel tiles.
+hipError_t launch_weight_grad16(int cnt, long long tiles_per_image, int n_rows, int g_ct, int x_ct, const void* G, const void* X, float* dW,
+                                float* colsum, const float* inv_scale, hipStream_t stream) {
+    if (cnt < 1 || tiles_per_image < 1 || n_rows < 1 || g_ct < 1 || x_ct < 1 || x_ct > 8 || n_rows > 32 * g_ct) return hipErrorInvalidValue;
+    const int noc = (n_rows + 31) / 32;
+    if (noc != 1 && noc != 2 && noc != 4 && noc != 8) return hipErrorInvalidValue;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+    long long bpi = cus / cnt;
+    if (bpi > tiles_per_image) bpi = tiles_per_image;
+    if (bpi < 1) bpi = 1;
+    WeightGrad16Args a{(const _Float16*)G, (const _Float16*)X, dW, colsum, inv_scale, tiles_per_image, cnt, g_ct, x_ct, 0, 32 * x_ct, n_rows, (int)bpi};
+    bool first = true;
+    for (int t0 = 0; t0 < x_ct;) {                           // column runs of 8, 4, 2, 1 channel tiles
+        int nj = 8;
+        while (nj > x_ct - t0) nj >>= 1;
+        a.x_t0 = t0;
+        WeightGrad16Args run = a;
+        if (!first) run.colsum = nullptr;                    // the column sums of G are accumulated by the first run only
+        hipError_t e = hipSuccess;
+        switch (noc) {
+            case 1: e = launch_wg16_noc<1>(run, nj, stream); break;
+            case 2: e = launch_wg16_noc<2>(run, nj, stream); break;
+            case 4: e = launch_wg16_noc<4>(run, nj, stream); break;
+            case 8: e = launch_wg16_noc<8>(run, nj, stream); break;
+        }
+        if (e != hipSuccess) return e;
+        first = false;
+        t0 += nj;
+    }
+    return hipSuccess;
+}
+
+
+// =====================================================================================================================
+// chain16: the gradient chain of the field network on v_mfma_f32_32x32x16_f16
+// =====================================================================================================================
+//   go' = d loss / d head pre-activation (sigmoid' applied)                            -> go16 (TB16, 1 channel tile, x S_go)
+//   g_h = W_head^T go'
+//   for slab m = last .. 0:   ga_m = g_h * cos(arg_m)                                  -> g16[m] (TB16, x S_m)
+//                             gp_m = ga_m * freq_m            (plain sine layers: freq = 1)
+//                             g_h  = W_m^T gp_m               (m = 0: the 32 channels of every input tile -> trilinear
+//                                                              scatter-add into the gradient volume, fp32 atomics)
+// Like the forward kernels, a wave owns a 32-point tile and the accumulator registers of one product are the B operand of
+// the next (channel = k).  All gradient VALUES live in fp32 registers in true units; fp16 appears only at the two conversion
+// points, each with a power-of-two scale:
+//   * MFMA B operand: per POINT dynamic -- column j of the product depends on column j of B only, so every lane scales its
+//     own point by T_j = 2^(14 - exponent of its largest |gp|) and un-scales its accumulators by 1 / (s_m T_j) (s_m: the
+//     pre-scale of the packed W_m^T); tiny-gradient points keep all 11 bits, nothing overflows;
+//   * stored g16[m]: one scale S_m per slab for the whole call (the weight-gradient kernel sums over points on the k axis and
+//     cannot un-scale per point), chosen by the caller from the slab's largest |ga| as sampled by a DRY run of this kernel
+//     over every k-th tile group (no stores, atomicMax per slab); fmed3 clamps what a sample might have missed.
+// Weight units (two 32-row output tiles of a transposed matrix: 2 * KCH KiB) are streamed through a double buffer in LDS
+// by LDS-DMA and shared by the block's four waves, which work on four tiles of one image in lockstep (one barrier per unit)
+// -- the scheme of field_h3.hip.  cos(arg_m) of the next slab is fetched into registers under the MFMAs of the current one.
+struct Chain16Args {
+    FieldArgs f;              // geometry, tiles, freq, flags, layer kinds, gradient volumes, grad_out / saved_out
+    const f16x8* units;       // transposed weight units in consumption order (pack_chain16)
+    const f16x8* head_t;      // head^T fragments (NT x 64 lanes)
+    const float* winv;        // device: 1 / s_m per slab (index m), then the head's
+    const float* scales;      // device: per slab m {S_m, 1 / S_m}, then {S_go, 1 / S_go}
+    const _Float16* cos16;    // TB16 (nslab, tiles, NT, 32, 32)
+    _Float16* g16;            // TB16 (nslab, tiles, NT, 32, 32)
+    _Float16* go16;           // TB16 (tiles, 1, 32, 32)
+    unsigned int* gmax;       // dry run: per slab the bits of max |ga| (non-negative floats order like their bits), then max |go'|
+    int nslab;
+    int dry;                  // 1: no stores, no scatter; only gmax
+    int group_step;           // process every group_step-th tile group of a block's range (dry-run sampling)
+};
+
+__device__ __forceinline__ float pow2_below_2p14(float vmax) {
+    // T = 2^(14 - e) with vmax = m 2^e, m in [0.5, 1): vmax * T in [2^13, 2^14).  vmax == 0 (or denormal) -> 1.
+    const int e = (int)((__float_as_uint(vmax) >> 23) & 255u) - 126;
+    const int te = 127 + 14 - e;
+    return (vmax >= 1e-30f && te > 0 && te < 255) ? __uint_as_float((uint32_t)te << 23) : 1.0f;
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void chain16_kernel(Chain16Args A) {
+    extern __shared__ __attribute__((aligned(16))) char smem_c[];
+    const FieldArgs& a = A.f;
+    constexpr int KCH = 2 * NT;                         // k-chunks of 16 per matrix row tile
+    constexpr int UNIT_FR = 2 * KCH * 64;               // f16x8 fragments per weight unit (two output tiles)
+    constexpr int PW = (2 * KCH) / 4;                   // 1-KiB pieces each wave copies per unit
+    f16x8* lds_units = reinterpret_cast<f16x8*>(smem_c);                                   // 2 slots
+    f16x8* lds_head = lds_units + 2 * UNIT_FR;                                              // NT * 64 fragments
+    float* lds_freq = reinterpret_cast<float*>(lds_head + NT * 64);                        // film_stride floats (image of the block)
+    float* s_g = lds_freq + (a.film_stride > 0 ? a.film_stride : 4);                       // [4][32][33] scatter transpose
+    int* s_base = reinterpret_cast<int*>(s_g + 4 * 32 * 33);                               // [4][32][8]
+    float* s_w = reinterpret_cast<float*>(s_base + 4 * 32 * 8);                            // [4][32][8]
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int j = lane & 31, h = lane >> 5;
+
+    const long long G = (a.tiles_per_image + 3) / 4;
+    const long long total_groups = (a.total_tiles / a.tiles_per_image) * G;
+    const int nblk = gridDim.x;
+    const int cls = blockIdx.x & 7, idx_in_cls = blockIdx.x >> 3;
+    const int blk_per_cls = (nblk + 7 - cls) / 8;
+    const long long g_begin = total_groups * cls / 8 + (long long)idx_in_cls * A.group_step, g_end = total_groups * (cls + 1) / 8;
+    const long long g_stride = (long long)blk_per_cls * A.group_step;
+    if (g_begin >= g_end) return;                                                          // block-uniform
+
+    const int n_l0_units = (a.n_in + 1) / 2;
+    const int n_units = (A.nslab - 1) * (NT / 2) + n_l0_units;
+    int dma_k = 0, dma_slot = 0, use_slot = 0;
+    auto dma_next = [&]() {
+        const f16x8* src = A.units + (size_t)dma_k * UNIT_FR + (size_t)wave_u * PW * 64 + lane;
+        f16x8* dst = lds_units + dma_slot * UNIT_FR + wave_u * PW * 64;
+#pragma unroll
+        for (int q = 0; q < PW; ++q)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + q * 64),
+                                             (__attribute__((address_space(3))) void*)(dst + q * 64), 16, 0, 0);
+        dma_k = dma_k + 1 == n_units ? 0 : dma_k + 1;
+        dma_slot ^= 1;
+    };
+    auto unit_begin = [&]() -> const f16x8* {           // every wave, at the start of every unit
+        __builtin_amdgcn_s_waitcnt(0x0F70);             // this wave's share of the unit has landed ...
+        __syncthreads();                                // ... everybody's has, and nobody still reads the other slot
+        dma_next();
+        const f16x8* u = lds_units + use_slot * UNIT_FR;
+        use_slot ^= 1;
+        return u;
+    };
+
+    for (int i = threadIdx.x; i < NT * 64; i += 256) lds_head[i] = A.head_t[i];
+    dma_next();
+    int staged_b = -1;
+    const float S_go = A.scales[2 * A.nslab], winv_head = A.winv[A.nslab];
+
+    for (long long g = g_begin; g < g_end; g += g_stride) {
+        const int b = (int)(g / G);
+        const long long tile_in_image = (g - (long long)b * G) * 4 + wave;
+        const bool live = tile_in_image < a.tiles_per_image;                               // wave-uniform
+        const long long n = tile_in_image * 32 + j;
+        const bool valid = live && n < a.n_per_image;
+        const long long nn = n < a.n_per_image ? n : a.n_per_image - 1;
+        const size_t gpt = (size_t)b * a.n_per_image + nn;
+        const long long tile_T = (long long)b * a.tiles_per_image + (live ? tile_in_image : a.tiles_per_image - 1);
+        const size_t slab16 = (size_t)a.total_tiles * NT * 1024;
+        const size_t row16 = ((size_t)tile_T * NT * 32 + j) * 32;                           // element (T, t = 0, j, 0) inside a slab
+        if (b != staged_b && a.freq) {                                                     // block-uniform
+            __syncthreads();
+            for (int i = threadIdx.x; i < a.film_stride; i += 256) lds_freq[i] = a.freq[(size_t)b * a.film_stride + i];
+            staged_b = b;
+            __syncthreads();
+        }
+        // cos of the last slab: in flight under the head product
+        f16x4 cosr[NT * 4];         // (indexed as fp16 elements: hipcc 7.2 mis-extracts bit_cast<f16x2>(u32x2[1]) as element 0)
+        auto fetch_cos = [&](int m) {
+            const _Float16* src = A.cos16 + (size_t)m * slab16 + row16 + 4 * h;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) cosr[4 * t + gq] = *reinterpret_cast<const f16x4*>(src + t * 1024 + 8 * gq);
+        };
+        fetch_cos(A.nslab - 1);
+
+        // ---- head backward -------------------------------------------------------------------------------------------
+        f32x4 go = *reinterpret_cast<const f32x4*>(a.grad_out + gpt * 4);
+        if (!valid) go = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (a.flags & CNERF_F_SIGMOID_RGB) {
+            const f32x4 so = *reinterpret_cast<const f32x4*>(a.saved_out + gpt * 4);
+            go[0] = go[0] * (so[0] * (1.0f - so[0]));
+            go[1] = go[1] * (so[1] * (1.0f - so[1]));
+            go[2] = go[2] * (so[2] * (1.0f - so[2]));
+        }
+        float gs[4], gl[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            gs[i] = __builtin_amdgcn_fmed3f(go[i] * S_go, -60000.0f, 60000.0f);
+            gl[i] = gs[i] - (float)(_Float16)gs[i];
+        }
+        if (A.dry) {
+            float m4 = fmaxf(fmaxf(fabsf(go[0]), fabsf(go[1])), fmaxf(fabsf(go[2]), fabsf(go[3])));
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) m4 = fmaxf(m4, __shfl_xor(m4, d, WAVE));
+            if (lane == 0) atomicMax(A.gmax + A.nslab, __float_as_uint(m4));
+        } else if (live && h == 0) {                    // row j of the tile's single channel block: channels 0..3 (the rest stays zero)
+            *reinterpret_cast<u32x2_*>(A.go16 + ((size_t)tile_T * 32 + j) * 32) = u32x2_{pk_f16(gs[0], gs[1]), pk_f16(gs[2], gs[3])};
+        }
+        f32x16 acc[NT];
+        {
+            // B fragment: element jj of lane half h is k = 8 h + jj; the head has 4 outputs (k < 4): half 0, elements 0..3
+            const u32x4 bh = h == 0 ? u32x4{pk_f16(gs[0], gs[1]), pk_f16(gs[2], gs[3]), 0u, 0u} : u32x4{0u, 0u, 0u, 0u};
+            const u32x4 bl = h == 0 ? u32x4{pk_f16(gl[0], gl[1]), pk_f16(gl[2], gl[3]), 0u, 0u} : u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                f32x16 z;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) z[r] = 0.0f;
+                const f16x8 aw = lds_head[t * 64 + lane];
+                z = __builtin_amdgcn_mfma_f32_32x32x16_f16(aw, __builtin_bit_cast(f16x8, bl), z, 0, 0, 0);
+                z = __builtin_amdgcn_mfma_f32_32x32x16_f16(aw, __builtin_bit_cast(f16x8, bh), z, 0, 0, 0);
+                acc[t] = z;
+            }
+        }
+        float U = winv_head / S_go;                      // accumulators -> true units
+
+        // ---- slabs, last to first ---------------------------------------------------------------------------------------
+        int film_idx = 0;
+        for (int l = 0; l < a.L; ++l) film_idx += (a.layer_kind[l] == CNERF_LAYER_FILM);
+        u32x4 frag[KCH];                                // B operand of the next product: k-chunk c = channels 16 c .. 16 c + 15
+        for (int m = A.nslab - 1; m >= 0; --m) {
+            const bool film = a.layer_kind[m] == CNERF_LAYER_FILM;
+            if (film) --film_idx;
+            const float* fr = film ? lds_freq + (size_t)film_idx * (NT * 32) : nullptr;
+            const float S_m = A.scales[2 * m];
+            // pass 1: ga = g_h cos (true units, kept in the accumulators), its store, the point's largest |gp|
+            float vmax = 0.0f, gmax_l = 0.0f;
+            _Float16* gdst = A.g16 + (size_t)m * slab16 + row16 + 4 * h;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const f16x4 cw = cosr[4 * t + gq];
+                    const float cv[4] = {(float)cw[0], (float)cw[1], (float)cw[2], (float)cw[3]};
+                    float ga[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        ga[e] = acc[t][4 * gq + e] * U * cv[e];
+                        acc[t][4 * gq + e] = ga[e];
+                        const float f = film ? fr[32 * t + 8 * gq + 4 * h + e] : 1.0f;
+                        vmax = fmaxf(vmax, fabsf(ga[e] * f));
+                        gmax_l = fmaxf(gmax_l, fabsf(ga[e]));
+                    }
+                    if (!A.dry && live) {
+                        float s4[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) s4[e] = __builtin_amdgcn_fmed3f(ga[e] * S_m, -65504.0f, 65504.0f);
+                        *reinterpret_cast<u32x2_*>(gdst + t * 1024 + 8 * gq) = u32x2_{pk_f16(s4[0], s4[1]), pk_f16(s4[2], s4[3])};
+                    }
+                }
+            }
+            if (A.dry) {
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) gmax_l = fmaxf(gmax_l, __shfl_xor(gmax_l, d, WAVE));
+                if (lane == 0) atomicMax(A.gmax + m, __float_as_uint(gmax_l));
+            }
+            if (m > 0) fetch_cos(m - 1);                 // lands under the MFMAs below
+            vmax = fmaxf(vmax, __shfl_xor(vmax, 32, WAVE));   // the two lane halves of a point share its scale
+            const float T = pow2_below_2p14(vmax);
+            // pass 2: the fp16 B operand, gp * T
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const int ch = 32 * t + 8 * (r >> 2) + 4 * h + (r & 3);
+                    const float f0 = film ? fr[ch] : 1.0f, f1 = film ? fr[ch + 1] : 1.0f;
+                    frag[2 * t + (r >> 3)][(r & 7) >> 1] = pk_f16(acc[t][r] * f0 * T, acc[t][r + 1] * f1 * T);
+                }
+            const float winv_m = A.winv[m];
+            U = winv_m / T;
+            if (m > 0) {
+                // g_h of slab m-1 = W_m^T gp_m: NT output tiles, two per weight unit
+#pragma unroll
+                for (int u = 0; u < NT / 2; ++u) {
+                    const f16x8* unit = unit_begin();
+#pragma unroll
+                    for (int sub = 0; sub < 2; ++sub) {
+                        f32x16 z;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) z[r] = 0.0f;
+#pragma unroll
+                        for (int c = 0; c < KCH; ++c)
+                            z = __builtin_amdgcn_mfma_f32_32x32x16_f16(unit[(sub * KCH + c) * 64 + lane], __builtin_bit_cast(f16x8, frag[c]), z, 0, 0, 0);
+                        acc[2 * u + sub] = z;
+                    }
+                }
+            }
+        }
+        // ---- layer 0: one 32-channel gradient tile per input tile; feature tiles are scattered, the xyz tile is dropped ----------
+        float px, py, pz;
+        tile_point(a, b, nn, valid, h, false, px, py, pz);
+        const int ch = lane & 31;
+        float* sg = s_g + wave * 32 * 33;
+        int* sb = s_base + wave * 32 * 8;
+        float* sw = s_w + wave * 32 * 8;
+        for (int u = 0; u < n_l0_units; ++u) {
+            const f16x8* unit = unit_begin();
+            for (int sub = 0; sub < 2; ++sub) {
+                const int tk = 2 * u + sub;
+                if (tk >= a.n_in) break;
+                const int lvl = a.in_level[tk];
+                if (lvl < 0 || A.dry) continue;                              // no gradient flows to the sample positions
+                f32x16 z;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) z[r] = 0.0f;
+#pragma unroll
+                for (int c = 0; c < KCH; ++c)
+                    z = __builtin_amdgcn_mfma_f32_32x32x16_f16(unit[(sub * KCH + c) * 64 + lane], __builtin_bit_cast(f16x8, frag[c]), z, 0, 0, 0);
+                const int V = a.lvl_V[lvl], C = a.lvl_C[lvl];
+                Corner8 cr;
+                trilinear_corners(px, py, pz, a.half_voxel, V, cr);
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) sg[j * 33 + 8 * gq + 4 * h + e] = z[4 * gq + e] * U;
+                if (h == 0) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        sb[j * 8 + k] = cr.base[k];
+                        sw[j * 8 + k] = valid ? cr.w[k] : 0.0f;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                float* gv = a.lvl_grad[lvl] + (size_t)b * V * V * V * C + a.in_chan[tk];
+                for (int pp = 0; pp < 16; ++pp) {
+                    const int p = 2 * pp + h;                  // two points per wave instruction, 32 channels each
+                    const float gval = sg[p * 33 + ch];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const float wk = sw[p * 8 + k];
+                        if (wk != 0.0f) atomicAdd(gv + (size_t)sb[p * 8 + k] * C + ch, gval * wk);
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();                                    // drain the copy issued for a unit this block does not consume
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// packing: transposed matrices as fp16 A fragments, scaled per matrix by a power of two (max |W| s = 2^14 .. 2^15)
+// ---------------------------------------------------------------------------------------------------------------
+// M = W^T (rows = inputs of the layer = outputs of the transposed product, K = H columns).  Fragment index inside the stream
+// of one matrix: ((t * KCH + c) * 64 + lane), t = output tile (padded to an even count with zero tiles), element jj of lane
+// (i = lane & 31, hh = lane >> 5) = s * M[32 t + i][16 c + 8 (jj >> 2) + 4 hh + (jj & 3)]: the k order in which the
+// accumulator registers of the previous product become the B operand (registers 8 s' .. 8 s' + 7 of tile t' are k-chunk
+// 2 t' + s': element jj <-> channel 32 t' + 16 s' + 8 (jj >> 2) + 4 hh + (jj & 3)).
+__global__ void absmax16_kernel(const float* __restrict__ w, long long n, uint32_t* slot) {
+    float m = 0.0f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(w[i]));
+#pragma unroll
+    for (int d = WAVE / 2; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, WAVE));
+    if ((threadIdx.x & 63) == 0 && m == m) atomicMax(slot, __float_as_uint(m));
+}
+
+__global__ void pack_t16_kernel(const float* __restrict__ w, int n_rows_w, int n_cols_w, int n_cols_real, int OT, int KCH, const uint32_t* wmax_slot,
+                                float* winv_slot, _Float16* __restrict__ dst) {
+    // w: (n_rows_w, n_cols_w) row-major = W; M[r][k] = W[k][r], r < n_cols_real (else 0), k < n_rows_w (= 16 * KCH)
+    const float wmax = __uint_as_float(*wmax_slot);
+    float s = 1.0f;
+    if (wmax > 1e-30f && wmax < 3e38f) {
+        int e;
+        (void)frexpf(16384.0f / wmax, &e);
+        s = ldexpf(1.0f, e - 1 > 100 ? 100 : e - 1);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) *winv_slot = 1.0f / s;
+    const long long total = (long long)OT * KCH * 64 * 8;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int jj = (int)(idx & 7), lane = (int)((idx >> 3) & 63);
+        const long long tc = idx >> 9;
+        const int c = (int)(tc % KCH), t = (int)(tc / KCH);
+        const int r = 32 * t + (lane & 31);
+        const int k = 16 * c + 8 * (jj >> 2) + 4 * (lane >> 5) + (jj & 3);
+        const float v = (r < n_cols_real && k < n_rows_w) ? w[(size_t)k * n_cols_w + r] * s : 0.0f;
+        dst[idx] = (_Float16)v;
+    }
+}
+
+// head^T: fragment (t * 64 + lane), element jj = s * W_head[k = 8 hh + jj][32 t + i] for k < 4, else 0
+__global__ void pack_head_t16_kernel(const float* __restrict__ w, int H, const uint32_t* wmax_slot, float* winv_slot, _Float16* __restrict__ dst) {
+    const float wmax = __uint_as_float(*wmax_slot);
+    float s = 1.0f;
+    if (wmax > 1e-30f && wmax < 3e38f) {
+        int e;
+        (void)frexpf(16384.0f / wmax, &e);
+        s = ldexpf(1.0f, e - 1 > 100 ? 100 : e - 1);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) *winv_slot = 1.0f / s;
+    const int total = (H / 32) * 64 * 8;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int jj = idx & 7, lane = (idx >> 3) & 63, t = idx >> 9;
+        const int k = 8 * (lane >> 5) + jj;
+        dst[idx] = (_Float16)(k < 4 ? w[(size_t)k * H + 32 * t + (lane & 31)] * s : 0.0f);
+    }
+}
+
+// One transposed matrix: OT output tiles (padded to even), KCH = rows of W / 16 chunks.  scratch: one uint32 per call.
+hipError_t launch_pack_t16(const float* w, int n_rows_w, int n_cols_w, int n_cols_real, int OT_padded, void* dst, float* winv_slot, uint32_t* wmax_slot,
+                           hipStream_t stream) {
+    if (hipError_t e = hipMemsetAsync(wmax_slot, 0, sizeof(uint32_t), stream)) return e;
+    const long long n = (long long)n_rows_w * n_cols_w;
+    long long rb = (n + 255) / 256;
+    if (rb > 256) rb = 256;
+    hipLaunchKernelGGL(absmax16_kernel, dim3((unsigned)rb), dim3(256), 0, stream, w, n, wmax_slot);
+    const int KCH = n_rows_w / 16;
+    const long long total = (long long)OT_padded * KCH * 64 * 8;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(pack_t16_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, w, n_rows_w, n_cols_w, n_cols_real, OT_padded, KCH, (const uint32_t*)wmax_slot,
+                       winv_slot, (_Float16*)dst);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_head_t16(const float* w, int H, void* dst, float* winv_slot, uint32_t* wmax_slot, hipStream_t stream) {
+    if (hipError_t e = hipMemsetAsync(wmax_slot, 0, sizeof(uint32_t), stream)) return e;
+    hipLaunchKernelGGL(absmax16_kernel, dim3(4), dim3(256), 0, stream, w, (long long)4 * H, wmax_slot);
+    hipLaunchKernelGGL(pack_head_t16_kernel, dim3((unsigned)((H / 32) * 2)), dim3(256), 0, stream, w, H, (const uint32_t*)wmax_slot, winv_slot, (_Float16*)dst);
+    return hipGetLastError();
+}
+
+struct Chain16Launch {
+    const void* units;
+    const void* head_t;
+    const float* winv;
+    const float* scales;
+    const void* cos16;
+    void* g16;
+    void* go16;
+    unsigned int* gmax;
+    int nslab, dry, group_step;
+};
+
+template <int NT>
+static hipError_t launch_chain16_nt(const FieldArgs& f, const Chain16Launch& c, hipStream_t stream) {
+    Chain16Args A;
+    A.f = f;
+    A.units = (const f16x8*)c.units;
+    A.head_t = (const f16x8*)c.head_t;
+    A.winv = c.winv;
+    A.scales = c.scales;
+    A.cos16 = (const _Float16*)c.cos16;
+    A.g16 = (_Float16*)c.g16;
+    A.go16 = (_Float16*)c.go16;
+    A.gmax = c.gmax;
+    A.nslab = c.nslab;
+    A.dry = c.dry;
+    A.group_step = c.group_step < 1 ? 1 : c.group_step;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+    const size_t lds_bytes = (size_t)2 * (2 * 2 * NT * 64) * 16 + (size_t)NT * 64 * 16 + (size_t)(f.film_stride > 0 ? f.film_stride : 4) * 4 +
+                             (size_t)4 * 32 * 33 * 4 + (size_t)2 * 4 * 32 * 8 * 4;
+    if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
+    if (hipError_t e = hipFuncSetAttribute((const void*)chain16_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)) return e;
+    const long long want = (f.total_tiles / f.tiles_per_image) * ((f.tiles_per_image + 3) / 4);
+    int blocks = (int)(want < cus ? want : cus);
+    if (blocks < 8) blocks = 8;
+    blocks = (blocks + 7) / 8 * 8;
+    hipLaunchKernelGGL((chain16_kernel<NT>), dim3(blocks), dim3(256), lds_bytes, stream, A);
+    return hipGetLastError();
+}
+
+hipError_t launch_chain16(const FieldArgs& f, int H, const void* units, const void* head_t, const float* winv, const float* scales, const void* cos16,
+                          void* g16, void* go16, unsigned int* gmax, int nslab, int dry, int group_step, hipStream_t stream) {
+    const Chain16Launch c{units, head_t, winv, scales, cos16, g16, go16, gmax, nslab, dry, group_step};
+    switch (H / 32) {
+        case 2: return launch_chain16_nt<2>(f, c, stream);
+        case 4: return launch_chain16_nt<4>(f, c, stream);
+        case 8: return launch_chain16_nt<8>(f, c, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace cnerf

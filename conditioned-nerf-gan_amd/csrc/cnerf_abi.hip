@@ -590,4 +590,148 @@ int cnerf_field_backward(const cnerf_cfg* cfg, int32_t pass, int32_t image0, int
     return CNERF_OK;
 }
 
+int cnerf_weight_grad16(int32_t n_images, int64_t tiles_per_image, int32_t n_rows, int32_t g_ct, int32_t x_ct, const void* G,
+                        const void* X, float* dW, float* colsum, const float* inv_scale, void* stream) {
+    g_err[0] = 0;
+    if (!G || !X || !dW) return fail(CNERF_EINVAL, "weight_grad16: NULL argument");
+    if (n_images < 1 || tiles_per_image < 1) return fail(CNERF_EINVAL, "weight_grad16: empty chunk");
+    const int noc = (n_rows + 31) / 32;
+    if (n_rows < 1 || (noc != 1 && noc != 2 && noc != 4 && noc != 8) || noc > g_ct || x_ct < 1 || x_ct > 8)
+        return fail(CNERF_EINVAL, "weight_grad16: n_rows=%d (1..256, 1/2/4/8 channel tiles), g_ct=%d, x_ct=%d (1..8) unsupported", n_rows, g_ct, x_ct);
+    if (hipError_t e = launch_weight_grad16(n_images, tiles_per_image, n_rows, g_ct, x_ct, G, X, dW, colsum, inv_scale, (hipStream_t)stream))
+        return hip_fail(e, "weight_grad16");
+    return CNERF_OK;
+}
+
+namespace {
+// packed16 layout: [transposed units of matrices n_mats-1 .. 1, then layer 0 (output tiles padded to even)][head^T: NT fragments
+// x 64 lanes][winv: n_mats + 1 floats][max|W| scratch: n_mats + 1 uint32], each section 256-byte aligned
+struct Chain16Layout {
+    size_t units_bytes, head_off, winv_off, wmax_off, total;
+    int n_mats, n_in, k0, ot0;
+};
+int chain16_layout(const cnerf_cfg* c, Chain16Layout& l) {
+    for (int i = 0; i < c->L; ++i)
+        if (c->layer_kind[i] != CNERF_LAYER_FILM && c->layer_kind[i] != CNERF_LAYER_SINE)
+            return fail(CNERF_ENOSYS, "half-precision backward: FiLM / plain-sine layers only (layer %d is kind %d)", i, c->layer_kind[i]);
+    const size_t NT = c->H / 32, KCH = 2 * NT, frag = 64 * 16;
+    const PackedLayout pl = packed_layout(c);
+    l.n_mats = c->L;
+    l.n_in = pl.n_in;
+    l.k0 = pl.k0;
+    l.ot0 = (pl.n_in + 1) / 2 * 2;
+    l.units_bytes = ((size_t)(c->L - 1) * NT + l.ot0) * KCH * frag;
+    l.head_off = align256(l.units_bytes);
+    l.winv_off = l.head_off + align256(NT * frag);
+    l.wmax_off = l.winv_off + align256((size_t)(c->L + 1) * sizeof(float));
+    l.total = l.wmax_off + align256((size_t)(c->L + 1) * sizeof(uint32_t));
+    return CNERF_OK;
+}
+}  // namespace
+
+int cnerf_backward16_bytes(const cnerf_cfg* cfg, size_t* packed16) {
+    g_err[0] = 0;
+    if (int rc = check_cfg(cfg, false)) return rc;
+    Chain16Layout l;
+    if (int rc = chain16_layout(cfg, l)) return rc;
+    if (packed16) *packed16 = l.total;
+    return CNERF_OK;
+}
+
+int cnerf_pack_field_chain16(const cnerf_cfg* cfg, const cnerf_field_params* p, void* packed16, void* stream_) {
+    g_err[0] = 0;
+    if (int rc = check_cfg(cfg, false)) return rc;
+    Chain16Layout l;
+    if (int rc = chain16_layout(cfg, l)) return rc;
+    if (!p || !packed16 || !p->w_final) return fail(CNERF_EINVAL, "pack_field_chain16: NULL argument");
+    hipStream_t stream = (hipStream_t)stream_;
+    const int H = cfg->H, NT = H / 32;
+    const size_t KCH = 2 * NT, frag = 64 * 16;
+    char* base = (char*)packed16;
+    float* winv = (float*)(base + l.winv_off);
+    uint32_t* wmax = (uint32_t*)(base + l.wmax_off);
+    char* dst = base;
+    for (int m = cfg->L - 1; m >= 1; --m) {          // consumption order of the chain
+        if (!p->w[m]) return fail(CNERF_EINVAL, "pack_field_chain16: layer %d weight is NULL", m);
+        if (hipError_t e = launch_pack_t16(p->w[m], H, H, H, NT, dst, winv + m, wmax + m, stream)) return hip_fail(e, "pack_t16");
+        dst += (size_t)NT * KCH * frag;
+    }
+    if (!p->w[0]) return fail(CNERF_EINVAL, "pack_field_chain16: layer 0 weight is NULL");
+    if (hipError_t e = launch_pack_t16(p->w[0], H, l.k0, l.k0, l.ot0, dst, winv + 0, wmax + 0, stream)) return hip_fail(e, "pack_t16");
+    if (hipError_t e = launch_pack_head_t16(p->w_final, H, base + l.head_off, winv + cfg->L, wmax + cfg->L, stream)) return hip_fail(e, "pack_head_t16");
+    return CNERF_OK;
+}
+
+int cnerf_field_backward16(const cnerf_cfg* cfg, uint32_t mode, int32_t group_step, int32_t pass, int32_t image0, int32_t n_images,
+                           const cnerf_volumes* vols, const float* packed, const void* packed16, const float* freq,
+                           const float* phase, const float* cam2world, const float* u_strat, const float* fine_z,
+                           const float* grad_rgb_sigma, const float* saved_rgb_sigma, void* act_feat16, void* act_h16, void* act_c16,
+                           void* act_g16, void* act_go16, const float* scales, uint32_t* gmax, const cnerf_grad_volumes* grad_vols,
+                           void* stream_) {
+    g_err[0] = 0;
+    if (int rc = check_cfg(cfg, true)) return rc;
+    Chain16Layout l;
+    if (int rc = chain16_layout(cfg, l)) return rc;
+    if (cfg->precision != CNERF_PREC_FP16X3) return fail(CNERF_EINVAL, "field_backward16: cfg->precision must be CNERF_PREC_FP16X3 (the re-run forward is that kernel)");
+    if (image0 < 0 || n_images < 1 || image0 + n_images > cfg->B) return fail(CNERF_EINVAL, "field_backward16: image range out of [0,B)");
+    if (pass < 0 || pass > 2) return fail(CNERF_EINVAL, "field_backward16: pass must be 0 (coarse), 1 (fine) or 2 (explicit points)");
+    if (!(mode & (CNERF_B16_STORE | CNERF_B16_DRY | CNERF_B16_CHAIN))) return fail(CNERF_EINVAL, "field_backward16: empty mode");
+    if (!vols || !packed || !packed16 || !cam2world || !act_feat16 || !act_h16 || !act_c16 || !scales)
+        return fail(CNERF_EINVAL, "field_backward16: NULL argument");
+    if ((mode & (CNERF_B16_DRY | CNERF_B16_CHAIN)) && (!grad_rgb_sigma || !saved_rgb_sigma)) return fail(CNERF_EINVAL, "field_backward16: the chain needs grad / saved rgb_sigma");
+    if ((mode & CNERF_B16_DRY) && !gmax) return fail(CNERF_EINVAL, "field_backward16: the dry run needs gmax");
+    if ((mode & CNERF_B16_CHAIN) && (!act_g16 || !act_go16 || !grad_vols)) return fail(CNERF_EINVAL, "field_backward16: the chain needs act_g16, act_go16, grad_vols");
+    if (mode & CNERF_B16_CHAIN)
+        for (int i = 0; i < n_levels_of(cfg); ++i)
+            if (!grad_vols->level[i]) return fail(CNERF_EINVAL, "field_backward16: gradient volume %d is NULL", i);
+    if (pass == 1 && !fine_z) return fail(CNERF_EINVAL, "field_backward16: the fine pass needs fine_z");
+    const PackedLayout pl = packed_layout(cfg);
+    if (pl.n_film && (!freq || !phase)) return fail(CNERF_EINVAL, "field_backward16: FiLM layers need freq and phase");
+    hipStream_t stream = (hipStream_t)stream_;
+    const long long npi = (long long)cfg->R * cfg->R * cfg->S;
+
+    FieldArgs fa;
+    if (int rc = fill_field_args(fa, cfg, vols, (mode & CNERF_B16_CHAIN) ? grad_vols : nullptr, packed, freq, phase, image0)) return rc;
+    set_points(fa, n_images, npi);
+    fa.cam2world = cam2world + (size_t)image0 * 16;
+    if (pass == 0) {
+        fa.mode = FIELD_MODE_COARSE;
+        fa.u_strat = u_strat ? u_strat + (size_t)image0 * npi : nullptr;
+    } else if (pass == 1) {
+        fa.mode = FIELD_MODE_FINE;
+        fa.fine_z = fine_z + (size_t)image0 * npi;
+    } else {
+        if (!u_strat) return fail(CNERF_EINVAL, "field_backward16: pass 2 takes the points (B,R*R*S,3) in the u_strat argument");
+        fa.mode = FIELD_MODE_POINTS;
+        fa.points = u_strat + (size_t)image0 * npi * 3;
+    }
+    const char* base16 = (const char*)packed16;
+    if (mode & CNERF_B16_STORE) {
+        if (!act_g16) return fail(CNERF_EINVAL, "field_backward16: the storing re-run uses act_g16 as scratch for its head output");
+        FieldArgs fs = fa;
+        fs.rgb_sigma = (float*)act_g16;      // (n,4) floats of head output nobody reads; the chain overwrites act_g16 entirely
+        fs.z_out = nullptr;
+        fs.act_points = (long long)n_images * npi;
+        fs.act_feat = (float*)act_feat16;
+        fs.act_h = (float*)act_h16;
+        fs.act_c = (float*)act_c16;
+        fs.act_tb16 = 1;
+        if (hipError_t e = launch_field_h3(fs, cfg->H, stream)) return hip_fail(e, "field kernel (fp16 activation store)");
+    }
+    fa.grad_out = grad_rgb_sigma ? grad_rgb_sigma + (size_t)image0 * npi * 4 : nullptr;
+    fa.saved_out = saved_rgb_sigma ? saved_rgb_sigma + (size_t)image0 * npi * 4 : nullptr;
+    const float* winv = (const float*)(base16 + l.winv_off);
+    if (mode & CNERF_B16_DRY) {
+        if (hipError_t e = launch_chain16(fa, cfg->H, base16, base16 + l.head_off, winv, scales, act_c16, nullptr, nullptr, gmax, l.n_mats, 1,
+                                          group_step < 1 ? 1 : group_step, stream))
+            return hip_fail(e, "chain16 (dry run)");
+    }
+    if (mode & CNERF_B16_CHAIN) {
+        if (hipError_t e = launch_chain16(fa, cfg->H, base16, base16 + l.head_off, winv, scales, act_c16, act_g16, act_go16, nullptr, l.n_mats, 0, 1,
+                                          stream))
+            return hip_fail(e, "chain16");
+    }
+    return CNERF_OK;
+}
+
 }  // extern "C"

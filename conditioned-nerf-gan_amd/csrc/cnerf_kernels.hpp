@@ -38,6 +38,7 @@ struct FieldArgs {
     float* act_feat;         // (n,32*n_in) layer-0 input tiles (looked-up features, xyz)
     float* act_h;            // (L,n,H) layer outputs sin(arg)
     float* act_c;            // (L,n,H) cos(arg)
+    int act_tb16;            // 1: act_feat / act_h / act_c are fp16 buffers in the TB16 layout (bwd16.hpp), written by field_h3_kernel
     // field_backward_kernel only
     const float* packed_t;   // transposed packed weights (cnerf_pack_field_transposed)
     const float* grad_out;   // (n,4) d loss / d rgb_sigma
@@ -152,5 +153,14 @@ hipError_t launch_scatter(const GatherArgs& a, const float* grad_feat, float* gr
 
 hipError_t launch_weight_grad(int cnt, long long npi, int H, int K, const float* G, const float* X, float* dW, float* colsum,
                               hipStream_t stream);
+
+// bwd16.hip
+hipError_t launch_pack_t16(const float* w, int n_rows_w, int n_cols_w, int n_cols_real, int OT_padded, void* dst, float* winv_slot, uint32_t* wmax_slot,
+                           hipStream_t stream);
+hipError_t launch_pack_head_t16(const float* w, int H, void* dst, float* winv_slot, uint32_t* wmax_slot, hipStream_t stream);
+hipError_t launch_chain16(const FieldArgs& f, int H, const void* units, const void* head_t, const float* winv, const float* scales, const void* cos16,
+                          void* g16, void* go16, unsigned int* gmax, int nslab, int dry, int group_step, hipStream_t stream);
+hipError_t launch_weight_grad16(int cnt, long long tiles_per_image, int n_rows, int g_ct, int x_ct, const void* G, const void* X, float* dW,
+                                float* colsum, const float* inv_scale, hipStream_t stream);
 
 }  // namespace cnerf

@@ -28,11 +28,10 @@
 #include "cnerf_dev.hpp"
 #include "cnerf_kernels.hpp"
 #include "field_common.hpp"
+#include "bwd16.hpp"
 
 namespace cnerf {
 
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 struct Split2 {          // eight fp32 values as two fp16 fragments; dword d of a fragment = elements 2d (low half), 2d+1
     u32x4 p[2];
@@ -151,7 +150,14 @@ struct ActStore {
     float* row_h;
     float* row_c;
     float ks[2], kc[2];      // the first pair of a quad, held until the second one arrives
+    // STORE == 2: fp16 in the TB16 layout (bwd16.hpp): the lane's row (point j) inside the 2-KiB block of channel tile 0 of
+    // the slab being produced; channel tile t is 1024 elements further on.  `live` is false for an idle wave (a tile past the
+    // end of its image: it has no block of its own).
+    _Float16* blk_h;
+    _Float16* blk_c;
+    bool live;
 };
+constexpr int STORE_NONE = 0, STORE_F32 = 1, STORE_TB16 = 2;
 
 // acc holds S * (W x) of accumulator elements r, r+1 (r even): pre = acc / S + bias in one rounding (S is a power of
 // two), FiLM with product and sum rounded separately like the reference (a plain sine layer runs with freq = 1,
@@ -163,7 +169,7 @@ __device__ __forceinline__ float half_hi(uint32_t u) { return (float)__builtin_b
 
 // RESID (second matrix of a residual block, siren.py:218-230): the slot the result goes to still holds the block's input
 // x as its two fp16 parts; x = hi + lo is added to W2 y + b2 before the sine, and the slot is overwritten.
-template <bool STORE, bool RESID>
+template <int STORE, bool RESID>
 __device__ __forceinline__ void film_split_pair(const f32x16& acc, float inv_s, const FilmPair& f, int t, int h, int r, Split2* out2,
                                                 ActStore& st) {
     float a0 = __builtin_fmaf(acc[r], inv_s, f.bs[0]), a1 = __builtin_fmaf(acc[r + 1], inv_s, f.bs[1]);
@@ -185,10 +191,14 @@ __device__ __forceinline__ void film_split_pair(const f32x16& acc, float inv_s, 
             st.ks[1] = v1;
             st.kc[0] = c0;
             st.kc[1] = c1;
-        } else {
+        } else if (STORE == STORE_F32) {
             const int ch = 32 * t + 8 * (r >> 2) + 4 * h;
             *reinterpret_cast<f32x4*>(st.row_h + ch) = f32x4{st.ks[0], st.ks[1], v0, v1};
             *reinterpret_cast<f32x4*>(st.row_c + ch) = f32x4{st.kc[0], st.kc[1], c0, c1};
+        } else if (st.live) {        // four consecutive channels of the lane's point: one 8-byte store per matrix
+            const int off = t * 1024 + 8 * (r >> 2) + 4 * h;
+            *reinterpret_cast<u32x2_*>(st.blk_h + off) = u32x2_{pk_f16(st.ks[0], st.ks[1]), pk_f16(v0, v1)};
+            *reinterpret_cast<u32x2_*>(st.blk_c + off) = u32x2_{pk_f16(st.kc[0], st.kc[1]), pk_f16(c0, c1)};
         }
     } else {
         v0 = sin_2pi_reduced_hw(a0);
@@ -204,7 +214,7 @@ __device__ __forceinline__ void film_split_pair(const f32x16& acc, float inv_s, 
 }
 
 // whole tile at once (layer 0 and the last output tile of a layer), FiLM pairs fetched one step ahead
-template <bool STORE, bool RESID>
+template <int STORE, bool RESID>
 __device__ __forceinline__ void film_split(const f32x16& acc, float inv_s, const float* lbias, const float* lfr, const float* lph, int t,
                                            int h, Split2* out2, ActStore& st) {
     FilmPair f = film_pair_load(lbias, lfr, lph, t, h, 0);
@@ -360,7 +370,7 @@ __device__ __forceinline__ TilePoint tile_of_group(const FieldArgs& a, long long
 
 // PAIRED: four LDS slots, one barrier per TWO weight units (single-input networks: the unit's parity inside the tile is then
 // static in the unrolled loops); otherwise two slots and a barrier per unit.
-template <int NT, bool STORE, bool PAIRED, bool HAS_RES>
+template <int NT, int STORE, bool PAIRED, bool HAS_RES>
 __global__ __launch_bounds__(256) void field_h3_kernel(FieldArgs a) {
 #ifdef CNERF_STAMPS
     unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -458,8 +468,15 @@ __global__ __launch_bounds__(256) void field_h3_kernel(FieldArgs a) {
         ActStore st;
         const size_t gpt = (size_t)b * a.n_per_image + nn;            // row of the lane's point in the chunk's activation buffers
         const size_t act_layer = (size_t)a.act_points * H;
-        st.row_h = STORE ? a.act_h + gpt * H : nullptr;
-        st.row_c = STORE ? a.act_c + gpt * H : nullptr;
+        st.row_h = STORE == STORE_F32 ? a.act_h + gpt * H : nullptr;
+        st.row_c = STORE == STORE_F32 ? a.act_c + gpt * H : nullptr;
+        // TB16: tile T = image * tiles_per_image + tile in image; an idle wave (tile past the image's last) stores nothing
+        const long long tile_in_image = (g - (long long)b * G) * 4 + wave;
+        const long long tile_T = (long long)b * a.tiles_per_image + tile_in_image;
+        const size_t slab16 = (size_t)a.total_tiles * NT * 1024;      // fp16 elements per slab (a.total_tiles = tiles of the chunk)
+        st.live = tile_in_image < a.tiles_per_image;
+        st.blk_h = STORE == STORE_TB16 ? reinterpret_cast<_Float16*>(a.act_h) + ((size_t)tile_T * NT * 32 + j) * 32 : nullptr;
+        st.blk_c = STORE == STORE_TB16 ? reinterpret_cast<_Float16*>(a.act_c) + ((size_t)tile_T * NT * 32 + j) * 32 : nullptr;
         // ---- layer 0: one weight unit per input tile ------------------------------------------------------------------
         {
             f32x16 acc0[NT];
@@ -478,10 +495,20 @@ __global__ __launch_bounds__(256) void field_h3_kernel(FieldArgs a) {
                 float fv[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) fv[r] = feat[r];
-                if (STORE) {
+                if (STORE == STORE_F32) {
                     float* fo = a.act_feat + gpt * (32 * a.n_in) + 32 * tk + 4 * h;
 #pragma unroll
                     for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4*>(fo + 8 * g) = f32x4{fv[4 * g], fv[4 * g + 1], fv[4 * g + 2], fv[4 * g + 3]};
+                }
+                if (STORE == STORE_TB16 && st.live) {        // layer-0 input tile tk, clamped to fp16's range like the MFMA operand
+                    _Float16* fo = reinterpret_cast<_Float16*>(a.act_feat) + (((size_t)tile_T * a.n_in + tk) * 32 + j) * 32 + 4 * h;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        float c4[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) c4[e] = __builtin_amdgcn_fmed3f(fv[4 * g + e], -65504.0f, 65504.0f);
+                        *reinterpret_cast<u32x2_*>(fo + 8 * g) = u32x2_{pk_f16(c4[0], c4[1]), pk_f16(c4[2], c4[3])};
+                    }
                 }
                 Split2 f2[2];
                 f2[0] = split8_clamped(fv);
@@ -493,9 +520,13 @@ __global__ __launch_bounds__(256) void field_h3_kernel(FieldArgs a) {
             const float inv_s = lds_inv_s[0];
 #pragma unroll
             for (int t = 0; t < NT; ++t) film_split<STORE, false>(acc0[t], inv_s, bias, film ? lfr : lds_ones, film ? lph : lds_zeros, t, h, &x[2 * t], st);
-            if (STORE) {
+            if (STORE == STORE_F32) {
                 st.row_h += act_layer;
                 st.row_c += act_layer;
+            }
+            if (STORE == STORE_TB16) {
+                st.blk_h += slab16;
+                st.blk_c += slab16;
             }
             bias += H;
             if (film) {
@@ -534,9 +565,13 @@ __global__ __launch_bounds__(256) void field_h3_kernel(FieldArgs a) {
                 acc_prev = acc;
             }
             film_split<STORE, RESID>(acc_prev, inv_s, bias, fr_l, ph_l, NT - 1, h, &out[2 * (NT - 1)], st);
-            if (STORE) {
+            if (STORE == STORE_F32) {
                 st.row_h += act_layer;
                 st.row_c += act_layer;
+            }
+            if (STORE == STORE_TB16) {
+                st.blk_h += slab16;
+                st.blk_c += slab16;
             }
             bias += H;
             ++m;
@@ -606,7 +641,7 @@ static size_t h3_lds_bytes(const FieldArgs& a, int slots) {
     return slots * (size_t)H3Lds<NT>::FRAGS * 16 + ((size_t)a.bias_floats + 2 * NT * 32 + 2 * (size_t)a.film_stride) * 4;
 }
 
-template <int NT, bool STORE, bool PAIRED, bool HAS_RES>
+template <int NT, int STORE, bool PAIRED, bool HAS_RES>
 static hipError_t launch_h3_inst(const FieldArgs& a, hipStream_t stream) {
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) != hipSuccess) dev = 0;
@@ -623,7 +658,7 @@ static hipError_t launch_h3_inst(const FieldArgs& a, hipStream_t stream) {
     return hipGetLastError();
 }
 
-template <int NT, bool STORE>
+template <int NT, int STORE>
 static hipError_t launch_h3_nt(const FieldArgs& a, hipStream_t stream) {
     // one barrier per two weight units where the unit parity is static (single-input networks) and four slots fit in LDS
     bool res = false;
@@ -635,11 +670,12 @@ static hipError_t launch_h3_nt(const FieldArgs& a, hipStream_t stream) {
 
 hipError_t launch_field_h3(const FieldArgs& a, int H, hipStream_t stream) {
     if (a.n_in < 1 || a.in_level[0] < 0) return hipErrorInvalidValue;      // the cross-tile lookup prefetch assumes a volume tile first
-    const bool store = a.act_h != nullptr;      // activation-storing forward of the backward pass
+    // a.act_h set: activation-storing forward of the backward pass, fp32 rows or (a.act_tb16) fp16 tile blocks
+    const int store = a.act_h == nullptr ? STORE_NONE : (a.act_tb16 ? STORE_TB16 : STORE_F32);
     switch (H / 32) {
-        case 2: return store ? launch_h3_nt<2, true>(a, stream) : launch_h3_nt<2, false>(a, stream);
-        case 4: return store ? launch_h3_nt<4, true>(a, stream) : launch_h3_nt<4, false>(a, stream);
-        case 8: return store ? launch_h3_nt<8, true>(a, stream) : launch_h3_nt<8, false>(a, stream);
+        case 2: return store == STORE_TB16 ? launch_h3_nt<2, STORE_TB16>(a, stream) : store ? launch_h3_nt<2, STORE_F32>(a, stream) : launch_h3_nt<2, STORE_NONE>(a, stream);
+        case 4: return store == STORE_TB16 ? launch_h3_nt<4, STORE_TB16>(a, stream) : store ? launch_h3_nt<4, STORE_F32>(a, stream) : launch_h3_nt<4, STORE_NONE>(a, stream);
+        case 8: return store == STORE_TB16 ? launch_h3_nt<8, STORE_TB16>(a, stream) : store ? launch_h3_nt<8, STORE_F32>(a, stream) : launch_h3_nt<8, STORE_NONE>(a, stream);
         default: return hipErrorInvalidValue;
     }
 }

@@ -605,9 +605,11 @@ __device__ __forceinline__ void bwd_matrix(const f32x4* __restrict__ wp, const f
 }
 
 // g_arg = g_h * cos(arg) (stored), g_pre = g_arg * freq       for all NT tiles of one layer
+// (`valid`: padded lanes of an image's last tile shadow its last point -- same row addresses -- with zero gradients; they must
+// not store, or their zeros race with the real row of that point)
 template <int NT>
 __device__ __forceinline__ void bwd_activation(f32x16* g, const float* __restrict__ row_c, float* __restrict__ row_g,
-                                               const float* __restrict__ freq, int h) {
+                                               const float* __restrict__ freq, int h, bool valid) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         f32x16 ga;
@@ -617,7 +619,7 @@ __device__ __forceinline__ void bwd_activation(f32x16* g, const float* __restric
 #pragma unroll
             for (int e = 0; e < 4; ++e) ga[4 * gq + e] = g[t][4 * gq + e] * c[e];
         }
-        store_tile_rows(row_g, t, h, ga);
+        if (valid) store_tile_rows(row_g, t, h, ga);
         const f32x16 fr = load_chan16(freq, t, h);
 #pragma unroll
         for (int r = 0; r < 16; ++r) g[t][r] = ga[r] * fr[r];
@@ -682,11 +684,11 @@ __global__ __launch_bounds__(256) void field_backward_kernel(FieldArgs a) {
             if (HAS_RES && kind == CNERF_LAYER_RES) {
                 // y = sin(W1 x + b1) [slab sub-1];  x' = sin(x + W2 y + b2) [slab sub]
                 float* row_gb = a.act_g + (size_t)sub * act_layer + gpt * H;
-                bwd_activation<NT>(g.v, a.act_c + (size_t)sub * act_layer + gpt * H, row_gb, ones, h);        // g = g_arg_b
+                bwd_activation<NT>(g.v, a.act_c + (size_t)sub * act_layer + gpt * H, row_gb, ones, h, valid);  // g = g_arg_b
                 bwd_matrix<NT, NT>(wp, g.v, g2.v, lane);                                                       // g2 = W2^T g_arg_b
                 wp += (size_t)NT * NT * TILE4;
                 bwd_activation<NT>(g2.v, a.act_c + (size_t)(sub - 1) * act_layer + gpt * H,
-                                   a.act_g + (size_t)(sub - 1) * act_layer + gpt * H, ones, h);                // g2 = g_arg_a
+                                   a.act_g + (size_t)(sub - 1) * act_layer + gpt * H, ones, h, valid);         // g2 = g_arg_a
                 bwd_matrix<NT, NT>(wp, g2.v, g.v, lane);                                                       // g = W1^T g_arg_a
                 wp += (size_t)NT * NT * TILE4;
 #pragma unroll
@@ -704,7 +706,7 @@ __global__ __launch_bounds__(256) void field_backward_kernel(FieldArgs a) {
             const bool film = kind == CNERF_LAYER_FILM;
             if (film) --film_idx;
             const float* fr = film ? a.freq + (size_t)b * a.film_stride + (size_t)film_idx * H : ones;
-            bwd_activation<NT>(g.v, a.act_c + (size_t)sub * act_layer + gpt * H, a.act_g + (size_t)sub * act_layer + gpt * H, fr, h);
+            bwd_activation<NT>(g.v, a.act_c + (size_t)sub * act_layer + gpt * H, a.act_g + (size_t)sub * act_layer + gpt * H, fr, h, valid);
             --sub;
             if (l > 0) {
                 bwd_matrix<NT, NT>(wp, g.v, g2.v, lane);

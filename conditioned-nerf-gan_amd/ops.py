@@ -19,6 +19,7 @@ def clear_pack_cache():
     parameters' version counters; bench.py calls this so that every timed step pays the packing like a training step)."""
     _pack_cache.clear()
     _packt_cache.clear()
+    _pack16_cache.clear()
 
 
 def _stream():
@@ -304,6 +305,7 @@ def pack_field_transposed(net, cfg):
     return packed_t
 
 
+DEBUG_CAPTURE = None            # set to a dict to capture the backward's chunk buffers (scripts/debug_b16.py)
 ACT_BUDGET_BYTES = 48 << 30     # activation / gradient chunk buffers of the backward (288 GB HBM per GPU)
 
 
@@ -358,8 +360,165 @@ def _pfilm_backward(net, cfg, levels, saved, gc, gf, hier):
     return [g_level], None, None, grads
 
 
+def backward_precision_of(net):
+    """Arithmetic of the backward's gradient GEMMs: `net.backward_precision` = "fp32" (exact fp32 MFMA chain and weight
+    gradients, the default) or "fp16" (fp16 operands, fp32 sums: the reference's own training numerics, utils.py:643 autocast);
+    "fp16" covers FiLM / plain-sine networks, the others run the fp32 path."""
+    p = getattr(net, "backward_precision", "fp32")
+    if p not in ("fp32", "fp16"):
+        raise L.CnerfError(f"unknown backward precision {p!r}")
+    if p == "fp16" and any(k not in ("film", "sine") for k in net.spec.layers):
+        return "fp32"
+    return p
+
+
+_pack16_cache = weakref.WeakKeyDictionary()
+
+
+def pack_field_chain16(net, cfg):
+    """Transposed fp16 weight units of the half-precision gradient chain (cnerf_pack_field_chain16), cached per parameter version."""
+    params = [_f32(p.detach()) for p in net.field_params()]
+    key = tuple((p.data_ptr(), p._version) for p in net.field_params())
+    hit = _pack16_cache.get(net)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    nb = C.c_size_t(0)
+    L.check(L.lib().cnerf_backward16_bytes(C.byref(cfg), C.byref(nb)), "cnerf_backward16_bytes")
+    packed16 = torch.empty(nb.value, dtype=torch.uint8, device=params[0].device)
+    fp = _field_params_struct(net, params)
+    L.check(L.lib().cnerf_pack_field_chain16(C.byref(cfg), C.byref(fp), L.ptr(packed16), _stream()), "cnerf_pack_field_chain16")
+    packed16._keepalive = params
+    _pack16_cache[net] = (key, packed16)
+    return packed16
+
+
+def _pow2_scales(gmax_bits):
+    """Per entry of the sampled maxima (uint32 bit patterns of non-negative floats): {S, 1/S} with S = 2^(11 - ceil(log2 max)) --
+    the sampled maximum lands in (2^10, 2^11], leaving a factor 32 to fp16's largest number for values the sample missed (the
+    kernel clamps beyond that); 1 where the maximum is 0.  Device ops only: no host round trip."""
+    gm = gmax_bits.view(torch.float32)
+    e = torch.ceil(torch.log2(gm.clamp_min(1e-30))).clamp(-100, 100)
+    S = torch.where(gm > 0, torch.exp2(11.0 - e), torch.ones_like(gm))
+    return torch.stack([S, 1.0 / S], -1).reshape(-1).contiguous()
+
+
+def _render_backward16(net, o, levels, freq, phase, cam2world, rng, saved, grad_pixels, grad_depth):
+    """render_backward with fp16 gradient GEMMs (see include/cnerf.h, "half-precision backward"): per chunk of images the
+    fp16x3 forward is re-run storing x0 / sin / cos as fp16 tile blocks, a sampled dry run of the chain finds each matrix'
+    gradient magnitude, the chain writes d/d(arg) as scaled fp16 tile blocks and scatters d/d(volume), and one fp16-MFMA
+    reduction per matrix forms G^T X and the column sums; dW, db, dfreq, dphase follow from those exactly as in the fp32 path."""
+    B, R, S, hier = o["B"], o["R"], o["S"], o["hier"]
+    dev = cam2world.device
+    cfg = make_cfg(net, B, levels, R, S, o["fov"], o["ray_start"], o["ray_end"], o["noise_std"], hier,
+                   o["white_back"], o["last_back"], o["clamp_mode"], precision="fp16x3")
+    vs = volumes_struct(levels)
+    packed = pack_field(net, cfg)
+    packed16 = pack_field_chain16(net, cfg)
+    H, k0 = int(net.hidden_dim), int(net.input_dim)
+    NT = H // 32
+    n_in = cfg.C // 32 + (1 if net.spec.input == "feat_xyz" else 0)
+    kinds = net.spec.layers
+    nslab = len(kinds)
+    npi = R * R * S
+    tpi = (npi + 31) // 32
+    c_rs, c_z, f_rs, f_z = saved[:4]
+    gc = torch.empty_like(c_rs)
+    gf = torch.empty_like(f_rs) if hier else None
+    grad_pixels = _f32(grad_pixels)
+    grad_depth = _f32(grad_depth) if grad_depth is not None else None
+    eps_final = _f32(rng.get("eps_final")) if o["noise_std"] != 0 else None
+    L.check(L.lib().cnerf_merge_composite_backward(C.byref(cfg), L.ptr(c_rs), L.ptr(c_z), L.ptr(f_rs) if hier else None,
+                                                   L.ptr(f_z) if hier else None, L.ptr(eps_final), L.ptr(grad_pixels),
+                                                   L.ptr(grad_depth), L.ptr(gc), L.ptr(gf) if hier else None, _stream()),
+            "cnerf_merge_composite_backward")
+    params = net.field_params()
+    Ws = [params[2 * l].detach() for l in range(nslab)]
+    bs = [params[2 * l + 1].detach() for l in range(nslab)]
+    W_head = params[2 * nslab].detach()
+    dW = [torch.zeros_like(w) for w in Ws]
+    db = [torch.zeros_like(b) for b in bs]
+    dW_head = torch.zeros_like(W_head)
+    db_head = torch.zeros(4, dtype=torch.float32, device=dev)
+    n_film = sum(1 for k in kinds if k == "film")
+    g_freq = torch.zeros((B, n_film * H), dtype=torch.float32, device=dev) if n_film else None
+    g_phase = torch.zeros_like(g_freq) if n_film else None
+    grad_levels = [torch.zeros_like(v) for v in levels]
+    gvs = volumes_struct(grad_levels)
+
+    per_image = tpi * 2048 * (n_in + 3 * nslab * NT + 1)
+    nb = max(1, min(B, ACT_BUDGET_BYTES // per_image))
+    groups = B * ((tpi + 3) // 4)
+    step = max(1, min(16, groups // 2048))          # dry-run sampling: every 16th tile group once there are plenty
+    u_strat = _f32(rng.get("u_strat"))
+    f16 = dict(dtype=torch.float16, device=dev)
+    act, act_T = None, -1
+    passes = [(0, gc, c_rs)] + ([(1, gf, f_rs)] if hier else [])
+    for pss, g_out, saved_out in passes:
+        for b0 in range(0, B, nb):
+            cnt = min(nb, B - b0)
+            T = cnt * tpi
+            if act_T != T:
+                act = (torch.empty((T, n_in, 32, 32), **f16), torch.empty((nslab, T, NT, 32, 32), **f16),
+                       torch.empty((nslab, T, NT, 32, 32), **f16), torch.empty((nslab, T, NT, 32, 32), **f16),
+                       torch.zeros((T, 1, 32, 32), **f16))
+                act_T = T
+            a_feat, a_h, a_c, a_g, a_go = act
+            gmax = torch.zeros(nslab + 1, dtype=torch.int32, device=dev)
+            # the head gradient's scale is known up front: |go'| <= |d loss / d rgb_sigma| (sigmoid' <= 1/4 only shrinks it)
+            go_scale = _pow2_scales(g_out[b0:b0 + cnt].abs().amax().reshape(1).view(torch.int32))
+            scales = torch.cat([torch.ones(2 * nslab, dtype=torch.float32, device=dev), go_scale])
+
+            def call(mode, group_step, scales_t):
+                L.check(L.lib().cnerf_field_backward16(C.byref(cfg), mode, group_step, pss, b0, cnt, C.byref(vs), L.ptr(packed), L.ptr(packed16),
+                                                       L.ptr(freq), L.ptr(phase), L.ptr(cam2world), L.ptr(u_strat),
+                                                       L.ptr(f_z) if hier else None, L.ptr(g_out), L.ptr(saved_out), L.ptr(a_feat), L.ptr(a_h),
+                                                       L.ptr(a_c), L.ptr(a_g), L.ptr(a_go), L.ptr(scales_t), L.ptr(gmax), C.byref(gvs), _stream()),
+                        "cnerf_field_backward16")
+
+            call(L.B16_STORE | L.B16_DRY, step, scales)
+            scales = torch.cat([_pow2_scales(gmax[:nslab]), go_scale])
+            call(L.B16_CHAIN, 1, scales)
+            if DEBUG_CAPTURE is not None:        # scripts/debug_b16.py: the chunk buffers of the first chunk of every pass
+                DEBUG_CAPTURE.setdefault(("b16", pss), dict(feat=a_feat.clone(), h=a_h.clone(), c=a_c.clone(), g=a_g.clone(), go=a_go.clone(),
+                                                            scales=scales.clone(), gmax=gmax.clone(), tpi=tpi, cnt=cnt))
+            fidx = 0
+            for l, kind in enumerate(kinds):
+                X = a_feat if l == 0 else a_h[l - 1]
+                x_ct = n_in if l == 0 else NT
+                dWarg = torch.zeros((cnt, H, 32 * x_ct), dtype=torch.float32, device=dev)   # per image: G^T X
+                cs = torch.zeros((cnt, H), dtype=torch.float32, device=dev)                 # per image: column sums of G
+                L.check(L.lib().cnerf_weight_grad16(cnt, tpi, H, NT, x_ct, L.ptr(a_g[l]), L.ptr(X), L.ptr(dWarg), L.ptr(cs),
+                                                    L.ptr(scales[2 * l + 1:2 * l + 2]), _stream()), "cnerf_weight_grad16")
+                if l == 0:
+                    dWarg = dWarg[..., :k0]                      # drop the zero padding of the last input tile
+                if kind == "film":
+                    sl = slice(fidx * H, (fidx + 1) * H)
+                    f = freq[b0:b0 + cnt, sl]
+                    dW[l] += (f.unsqueeze(-1) * dWarg).sum(0)
+                    db[l] += (f * cs).sum(0)
+                    g_phase[b0:b0 + cnt, sl] += cs
+                    g_freq[b0:b0 + cnt, sl] += (Ws[l].unsqueeze(0) * dWarg).sum(-1) + bs[l].unsqueeze(0) * cs
+                    fidx += 1
+                else:
+                    dW[l] += dWarg.sum(0)
+                    db[l] += cs.sum(0)
+            dWh = torch.zeros((cnt, 4, H), dtype=torch.float32, device=dev)
+            csh = torch.zeros((cnt, 4), dtype=torch.float32, device=dev)
+            L.check(L.lib().cnerf_weight_grad16(cnt, tpi, 4, 1, NT, L.ptr(a_go), L.ptr(a_h[nslab - 1]), L.ptr(dWh), L.ptr(csh),
+                                                L.ptr(scales[2 * nslab + 1:2 * nslab + 2]), _stream()), "cnerf_weight_grad16 (head)")
+            dW_head += dWh.sum(0)
+            db_head += csh.sum(0)
+    grads = []
+    for l in range(nslab):
+        grads += [dW[l], db[l]]
+    grads += [dW_head, db_head]
+    return grad_levels, g_freq, g_phase, grads
+
+
 def render_backward(net, o, levels, freq, phase, cam2world, rng, saved, grad_pixels, grad_depth):
     """Gradients of one render w.r.t. (channel-last feature volumes, freq, phase, [field parameters])."""
+    if backward_precision_of(net) == "fp16":
+        return _render_backward16(net, o, levels, freq, phase, cam2world, rng, saved, grad_pixels, grad_depth)
     B, R, S, hier = o["B"], o["R"], o["S"], o["hier"]
     dev = cam2world.device
     # cfg: precision of the forward (the activation-storing re-run follows it); cfg32: the fp32 gradient chain
@@ -437,6 +596,8 @@ def render_backward(net, o, levels, freq, phase, cam2world, rng, saved, grad_pix
                                                  L.ptr(fine_z_used) if hier else None, L.ptr(g_out), L.ptr(saved_out),
                                                  L.ptr(a_feat), L.ptr(a_h), L.ptr(a_c), L.ptr(a_g), L.ptr(a_go),
                                                  C.byref(gvs), _stream()), "cnerf_field_backward")
+            if DEBUG_CAPTURE is not None:
+                DEBUG_CAPTURE.setdefault(("f32", pss), dict(feat=a_feat.clone(), h=a_h.clone(), c=a_c.clone(), g=a_g.clone(), go=a_go.clone(), cnt=cnt))
             # parameter gradients: plain GEMMs and column sums over the chunk matrices (rocBLAS through torch)
             fidx = 0
             for l, kind in enumerate(slab_of):

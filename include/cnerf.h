@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define CNERF_ABI_VERSION 3
+#define CNERF_ABI_VERSION 4
 
 #define CNERF_OK 0
 #define CNERF_EINVAL (-22)  /* bad argument / unsupported shape (message via cnerf_last_error) */
@@ -246,6 +246,47 @@ int cnerf_weight_grad(int32_t n_images, int64_t n_per_image, int32_t H, int32_t 
 int cnerf_scatter_features(const cnerf_cfg* cfg, const float* points, int64_t n_per_image, const float* grad_feat,
                            float* grad_fvol_cl, void* stream);
 
+/* ---- half-precision backward (ABI v4): the counterpart of the reference's fp16 autocast training (utils.py:643-711) ------
+ * Activations and their gradients travel in fp16, every sum is fp32.  Buffers use the TB16 layout: a matrix with one row per
+ * sample point and 32 * CT channels is stored per 32-point tile (the field kernels' work unit: image b, tile k of
+ * tiles_per_image = ceil(R*R*S / 32), T = b * tiles_per_image + k) and per 32-channel tile as a dense 32 x 32 fp16 block:
+ *     element (T, t, j, c) -> fp16 index ((T * CT + t) * 32 + j) * 32 + c.
+ * Rows past the end of an image are rows of their own (gradient rows there are written as zeros). */
+
+/* dW[b] (n_rows, 32 * x_ct) += G[b]^T X[b] and colsum[b] (n_rows) += column sums of G[b], per image b < n_images, over the
+ * tiles of that image; G: TB16 with g_ct channel tiles of which the first ceil(n_rows / 32) are used (n_rows = 4 for the head:
+ * dW_head = go'^T x_L), X: TB16 with x_ct <= 8 channel tiles.  G holds scale * g; inv_scale (DEVICE scalar, may be NULL = 1)
+ * undoes it.  Outputs are accumulated into (zero them first); colsum may be NULL.  Autograd of nn.Linear inside
+ * FiLMLayer / SirenLayer (siren.py:146-199) like cnerf_weight_grad, on v_mfma_f32_32x32x16_f16. */
+int cnerf_weight_grad16(int32_t n_images, int64_t tiles_per_image, int32_t n_rows, int32_t g_ct, int32_t x_ct, const void* G,
+                        const void* X, float* dW, float* colsum, const float* inv_scale, void* stream);
+
+/* Packed operands of the half-precision gradient chain: every W_l^T (and the head's) as fp16 MFMA fragments, each matrix
+ * pre-scaled by a power of two, plus their inverse scales.  Bytes via cnerf_backward16_bytes.  FiLM / plain-sine layers
+ * (CNERF_ENOSYS for residual blocks and the per-point FiLM family: use the fp32 backward there). */
+int cnerf_backward16_bytes(const cnerf_cfg* cfg, size_t* packed16);
+int cnerf_pack_field_chain16(const cnerf_cfg* cfg, const cnerf_field_params* params, void* packed16, void* stream);
+
+/* cnerf_field_backward16.mode */
+#define CNERF_B16_STORE 1u /* re-run the field forward (fp16x3 kernel) storing x0, sin(arg_m), cos(arg_m) as fp16 TB16 */
+#define CNERF_B16_DRY 2u   /* run the chain over every `group_step`-th tile group WITHOUT stores: only gmax[m] = max |d/d arg_m| */
+#define CNERF_B16_CHAIN 4u /* the chain: g16, go16, feature-volume gradients */
+
+/* Twin of cnerf_field_backward (same pass / image-range / per-image-input conventions) for the half-precision path.
+ *   cfg->precision must be CNERF_PREC_FP16X3 and `packed` its forward layout (the re-run is that kernel);
+ *   act_feat16 (T, n_in, 32, 32), act_h16 / act_c16 / act_g16 (n_mats, T, H/32, 32, 32), act_go16 (T, 1, 32, 32; ZERO it
+ *   first: only channels 0..3 are written): fp16 TB16 chunk buffers, T = n_images * ceil(R*R*S / 32);
+ *   scales (DEVICE, 2 * (n_mats + 1) floats): per matrix m {S_m, 1 / S_m} = power-of-two scale of act_g16[m], then
+ *   {S_go, 1 / S_go} of act_go16 -- the caller derives them from gmax;  gmax (DEVICE, n_mats + 1 uint32, zero it first): bit
+ *   patterns of the sampled maxima written by a CNERF_B16_DRY call (max |d/d arg_m| per matrix, then max |go'|).
+ * Typical sequence per chunk: STORE | DRY (group_step 16)  ->  scales from gmax  ->  CHAIN  ->  cnerf_weight_grad16 per matrix
+ * (G = act_g16[m], X = act_feat16 or act_h16[m-1]; head: G = act_go16, n_rows 4, X = act_h16[last]). */
+int cnerf_field_backward16(const cnerf_cfg* cfg, uint32_t mode, int32_t group_step, int32_t pass, int32_t image0, int32_t n_images,
+                           const cnerf_volumes* vols, const float* packed, const void* packed16, const float* freq,
+                           const float* phase, const float* cam2world, const float* u_strat, const float* fine_z,
+                           const float* grad_rgb_sigma, const float* saved_rgb_sigma, void* act_feat16, void* act_h16, void* act_c16,
+                           void* act_g16, void* act_go16, const float* scales, uint32_t* gmax, const cnerf_grad_volumes* grad_vols,
+                           void* stream);
 
 #ifdef __cplusplus
 }

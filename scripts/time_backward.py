@@ -8,6 +8,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 dev = torch.device("cuda:0"); torch.manual_seed(0)
 gen = ImplicitGenerator3d("SHORTSIREN_FG", 256, 32, 4, 256).to(dev); gen.set_device(dev)
 gen.siren.precision = sys.argv[2] if len(sys.argv) > 2 else "fp32"
+gen.siren.backward_precision = sys.argv[3] if len(sys.argv) > 3 else "fp32"
 fvol = torch.randn(B, 32, 64, 64, 64, device=dev, requires_grad=True); glob = torch.randn(B, 256, device=dev, requires_grad=True)
 cam = torch.eye(4, device=dev).unsqueeze(0).repeat(B, 1, 1); cam[:, 2, 3] = -1.0
 def step(bwd):
@@ -20,5 +21,5 @@ for bwd in (False, True):
     n = 3
     for _ in range(n): step(bwd)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
-    print(f"{gen.siren.precision} B={B} {'fwd+bwd' if bwd else 'fwd    '}: {dt*1e3:8.1f} ms/step  {B*128*128/dt/1e6:.3f} M rays/s  peak mem {torch.cuda.max_memory_allocated()/2**30:.1f} GiB", flush=True)
+    print(f"{gen.siren.precision} bwd {gen.siren.backward_precision} B={B} {'fwd+bwd' if bwd else 'fwd    '}: {dt*1e3:8.1f} ms/step  {B*128*128/dt/1e6:.3f} M rays/s  peak mem {torch.cuda.max_memory_allocated()/2**30:.1f} GiB", flush=True)
 print("grad norms", fvol.grad.norm().item(), glob.grad.norm().item(), gen.siren.network[0].layer.weight.grad.norm().item())
