@@ -44,8 +44,12 @@ AUX_FIELDS = ("coarse_points", "coarse_z", "coarse_rgb_sigma", "coarse_weights",
               "fine_rgb_sigma", "sort_idx", "final_weights", "fine_points")
 
 
+class Act16(C.Structure):
+    _fields_ = [("feat", C.c_void_p), ("h", C.c_void_p), ("c", C.c_void_p)]
+
+
 class Aux(C.Structure):
-    _fields_ = [(k, C.c_void_p) for k in AUX_FIELDS] + [("field_events", C.c_void_p * 4)]
+    _fields_ = [(k, C.c_void_p) for k in AUX_FIELDS] + [("field_events", C.c_void_p * 4), ("act16", Act16 * 2)]
 
 
 # name -> (restype, argtypes); every symbol include/cnerf.h declares

@@ -243,8 +243,8 @@ __global__ __launch_bounds__(256) void chain16_kernel(Chain16Args A) {
     constexpr int KCH = 2 * NT;                         // k-chunks of 16 per matrix row tile
     constexpr int UNIT_FR = 2 * KCH * 64;               // f16x8 fragments per weight unit (two output tiles)
     constexpr int PW = (2 * KCH) / 4;                   // 1-KiB pieces each wave copies per unit
-    f16x8* lds_units = reinterpret_cast<f16x8*>(smem_c);                                   // 2 slots
-    f16x8* lds_head = lds_units + 2 * UNIT_FR;                                              // NT * 64 fragments
+    f16x8* lds_units = reinterpret_cast<f16x8*>(smem_c);                                   // 3 slots
+    f16x8* lds_head = lds_units + 3 * UNIT_FR;                                              // NT * 64 fragments
     float* lds_freq = reinterpret_cast<float*>(lds_head + NT * 64);                        // film_stride floats (image of the block)
     float* s_g = lds_freq + (a.film_stride > 0 ? a.film_stride : 4);                       // [4][32][33] scatter transpose
     int* s_base = reinterpret_cast<int*>(s_g + 4 * 32 * 33);                               // [4][32][8]
@@ -265,6 +265,10 @@ __global__ __launch_bounds__(256) void chain16_kernel(Chain16Args A) {
 
     const int n_l0_units = (a.n_in + 1) / 2;
     const int n_units = (A.nslab - 1) * (NT / 2) + n_l0_units;
+    // Weight units travel through a ring of THREE LDS slots: unit k + 2 is requested when unit k starts, so a copy has two
+    // units' worth of MFMAs (2 x 1024 cycles at H = 256) to land -- with two slots (one unit ahead) every unit began with
+    // ~0.5 us of waiting for its copy (32 single-pass MFMAs per unit do not cover an L2 round trip; the forward's three-pass
+    // units do).
     int dma_k = 0, dma_slot = 0, use_slot = 0;
     auto dma_next = [&]() {
         const f16x8* src = A.units + (size_t)dma_k * UNIT_FR + (size_t)wave_u * PW * 64 + lane;
@@ -274,18 +278,26 @@ __global__ __launch_bounds__(256) void chain16_kernel(Chain16Args A) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + q * 64),
                                              (__attribute__((address_space(3))) void*)(dst + q * 64), 16, 0, 0);
         dma_k = dma_k + 1 == n_units ? 0 : dma_k + 1;
-        dma_slot ^= 1;
+        dma_slot = dma_slot == 2 ? 0 : dma_slot + 1;
     };
-    auto unit_begin = [&]() -> const f16x8* {           // every wave, at the start of every unit
-        __builtin_amdgcn_s_waitcnt(0x0F70);             // this wave's share of the unit has landed ...
-        __syncthreads();                                // ... everybody's has, and nobody still reads the other slot
+    // every wave, at the start of every unit: wait for this wave's share of the unit's copy -- vmcnt retires in order, so
+    // "all but the PW pieces of the NEXT unit's copy" -- then the barrier (everybody's share has landed, nobody still reads the
+    // slot about to be refilled), then request the unit after next.  `young`: behind the two copies in flight the wave has
+    // just issued the g16 stores of a slab and the cos loads of the next one (up to 64 operations, more than vmcnt can
+    // express on top of PW): waiting down to 63 outstanding retires both copies (requested long ago) and leaves those in
+    // flight under the MFMAs instead of stalling on them.
+    auto unit_begin = [&](bool young) -> const f16x8* {
+        if (young) __builtin_amdgcn_s_waitcnt(0xCF7F);          // vmcnt(63)
+        else __builtin_amdgcn_s_waitcnt(0x0F70 | PW);           // vmcnt(PW), PW <= 8
+        __syncthreads();
         dma_next();
         const f16x8* u = lds_units + use_slot * UNIT_FR;
-        use_slot ^= 1;
+        use_slot = use_slot == 2 ? 0 : use_slot + 1;
         return u;
     };
 
     for (int i = threadIdx.x; i < NT * 64; i += 256) lds_head[i] = A.head_t[i];
+    dma_next();
     dma_next();
     int staged_b = -1;
     const float S_go = A.scales[2 * A.nslab], winv_head = A.winv[A.nslab];
@@ -386,7 +398,11 @@ __global__ __launch_bounds__(256) void chain16_kernel(Chain16Args A) {
                         vmax = fmaxf(vmax, fabsf(ga[e] * f));
                         gmax_l = fmaxf(gmax_l, fabsf(ga[e]));
                     }
+#ifdef C16_NOSTORE
+                    if (false) {
+#else
                     if (!A.dry && live) {
+#endif
                         float s4[4];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) s4[e] = __builtin_amdgcn_fmed3f(ga[e] * S_m, -65504.0f, 65504.0f);
@@ -417,7 +433,7 @@ __global__ __launch_bounds__(256) void chain16_kernel(Chain16Args A) {
                 // g_h of slab m-1 = W_m^T gp_m: NT output tiles, two per weight unit
 #pragma unroll
                 for (int u = 0; u < NT / 2; ++u) {
-                    const f16x8* unit = unit_begin();
+                    const f16x8* unit = unit_begin(u == 0);
 #pragma unroll
                     for (int sub = 0; sub < 2; ++sub) {
                         f32x16 z;
@@ -439,7 +455,7 @@ __global__ __launch_bounds__(256) void chain16_kernel(Chain16Args A) {
         int* sb = s_base + wave * 32 * 8;
         float* sw = s_w + wave * 32 * 8;
         for (int u = 0; u < n_l0_units; ++u) {
-            const f16x8* unit = unit_begin();
+            const f16x8* unit = unit_begin(u == 0 && A.nslab > 0);
             for (int sub = 0; sub < 2; ++sub) {
                 const int tk = 2 * u + sub;
                 if (tk >= a.n_in) break;
@@ -474,7 +490,9 @@ __global__ __launch_bounds__(256) void chain16_kernel(Chain16Args A) {
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
                         const float wk = sw[p * 8 + k];
+#ifndef C16_NOSCATTER
                         if (wk != 0.0f) atomicAdd(gv + (size_t)sb[p * 8 + k] * C + ch, gval * wk);
+#endif
                     }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -597,7 +615,7 @@ static hipError_t launch_chain16_nt(const FieldArgs& f, const Chain16Launch& c, 
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) != hipSuccess) dev = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
-    const size_t lds_bytes = (size_t)2 * (2 * 2 * NT * 64) * 16 + (size_t)NT * 64 * 16 + (size_t)(f.film_stride > 0 ? f.film_stride : 4) * 4 +
+    const size_t lds_bytes = (size_t)3 * (2 * 2 * NT * 64) * 16 + (size_t)NT * 64 * 16 + (size_t)(f.film_stride > 0 ? f.film_stride : 4) * 4 +
                              (size_t)4 * 32 * 33 * 4 + (size_t)2 * 4 * 32 * 8 * 4;
     if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
     if (hipError_t e = hipFuncSetAttribute((const void*)chain16_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)) return e;

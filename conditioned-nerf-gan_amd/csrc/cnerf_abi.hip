@@ -451,6 +451,20 @@ int cnerf_render_forward(const cnerf_cfg* cfg, const cnerf_volumes* vols, const 
     auto mark = [&](int i) {
         if (aux && aux->field_events[i]) (void)hipEventRecord((hipEvent_t)aux->field_events[i], stream);
     };
+    const bool keep = aux && aux->act16[0].h;
+    if (keep) {
+        if (cfg->precision != CNERF_PREC_FP16X3) return fail(CNERF_EINVAL, "render_forward: act16 needs precision CNERF_PREC_FP16X3");
+        if (!aux->act16[0].feat || !aux->act16[0].c || (hier && (!aux->act16[1].feat || !aux->act16[1].h || !aux->act16[1].c)))
+            return fail(CNERF_EINVAL, "render_forward: act16 is incomplete");
+    }
+    auto keep_pass = [&](int i) {
+        fa.act_points = (long long)cfg->B * npi;
+        fa.act_feat = keep ? (float*)aux->act16[i].feat : nullptr;
+        fa.act_h = keep ? (float*)aux->act16[i].h : nullptr;
+        fa.act_c = keep ? (float*)aux->act16[i].c : nullptr;
+        fa.act_tb16 = keep ? 1 : 0;
+    };
+    keep_pass(0);
     mark(0);
     if (hipError_t e = launch_forward(fa, cfg, stream)) return hip_fail(e, "field kernel (coarse)");
     mark(1);
@@ -469,6 +483,7 @@ int cnerf_render_forward(const cnerf_cfg* cfg, const cnerf_volumes* vols, const 
         fa.rgb_sigma = f_rs;
         fa.z_out = nullptr;
         fa.points_out = aux ? aux->fine_points : nullptr;
+        keep_pass(1);
         mark(2);
         if (hipError_t e = launch_forward(fa, cfg, stream)) return hip_fail(e, "field kernel (fine)");
         mark(3);

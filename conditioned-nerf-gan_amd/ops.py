@@ -239,7 +239,7 @@ HIER_ONLY = {"coarse_weights", "cdf", "inds", "fine_z", "fine_rgb_sigma", "sort_
 
 def render_forward(net, fvol, freq, phase, cam2world, img_size, fov, ray_start, ray_end, num_steps, hierarchical,
                    clamp_mode, noise_std, white_back=False, last_back=False, rng: Optional[dict] = None,
-                   want_aux=False, fvol_is_channel_last=False, field_events=None, aux_keys=None):
+                   want_aux=False, fvol_is_channel_last=False, field_events=None, aux_keys=None, act16=None):
     """ImplicitGenerator3d.forward on the GPU.  rng: dict with u_strat / eps_coarse / u_fine / eps_final tensors.
     field_events: optional 4 hipEvent_t handles (ints) recorded around the two field-kernel launches."""
     cam2world = _f32(cam2world)
@@ -275,6 +275,10 @@ def render_forward(net, fvol, freq, phase, cam2world, img_size, fov, ray_start, 
         aux_s = aux_s if aux_s is not None else L.Aux()
         for i, ev in enumerate(field_events):
             aux_s.field_events[i] = ev
+    if act16 is not None:          # keep the field passes' activations (fp16 tile blocks) for the half-precision backward
+        aux_s = aux_s if aux_s is not None else L.Aux()
+        for i, bufs in enumerate(act16):
+            aux_s.act16[i].feat, aux_s.act16[i].h, aux_s.act16[i].c = (t.data_ptr() for t in bufs)
     L.check(L.lib().cnerf_render_forward(C.byref(cfg), C.byref(vs), L.ptr(packed), L.ptr(_f32(freq)), L.ptr(_f32(phase)),
                                          L.ptr(cam2world), C.byref(r), L.ptr(pixels), L.ptr(depth),
                                          C.byref(aux_s) if aux_s is not None else None, L.ptr(ws), _stream()),
@@ -402,7 +406,26 @@ def _pow2_scales(gmax_bits):
     return torch.stack([S, 1.0 / S], -1).reshape(-1).contiguous()
 
 
-def _render_backward16(net, o, levels, freq, phase, cam2world, rng, saved, grad_pixels, grad_depth):
+RESIDENT_BUDGET_BYTES = 160 << 30    # fp16 activations kept from the forward for the backward (288 GB of HBM per GPU)
+
+
+def resident_act16(net, levels, B, R, S, hier, dev):
+    """fp16 tile-block buffers that keep the activations of the forward's field passes for the half-precision backward (one
+    set per pass: x0, sin, cos), or None when they would not fit the budget -- the backward then re-computes them chunk-wise."""
+    H, NT = int(net.hidden_dim), int(net.hidden_dim) // 32
+    n_in = sum(int(t.shape[-1]) for t in levels) // 32 + (1 if net.spec.input == "feat_xyz" else 0)
+    nslab = len(net.spec.layers)
+    T = B * ((R * R * S + 31) // 32)
+    n_pass = 2 if hier else 1
+    per_pass = T * 2048 * (n_in + 2 * nslab * NT)
+    if n_pass * per_pass + T * 2048 * (nslab * NT + 1) > RESIDENT_BUDGET_BYTES:
+        return None
+    f16 = dict(dtype=torch.float16, device=dev)
+    return [(torch.empty((T, n_in, 32, 32), **f16), torch.empty((nslab, T, NT, 32, 32), **f16), torch.empty((nslab, T, NT, 32, 32), **f16))
+            for _ in range(n_pass)]
+
+
+def _render_backward16(net, o, levels, freq, phase, cam2world, rng, saved, grad_pixels, grad_depth, act16=None):
     """render_backward with fp16 gradient GEMMs (see include/cnerf.h, "half-precision backward"): per chunk of images the
     fp16x3 forward is re-run storing x0 / sin / cos as fp16 tile blocks, a sampled dry run of the chain finds each matrix'
     gradient magnitude, the chain writes d/d(arg) as scaled fp16 tile blocks and scatters d/d(volume), and one fp16-MFMA
@@ -446,7 +469,7 @@ def _render_backward16(net, o, levels, freq, phase, cam2world, rng, saved, grad_
     gvs = volumes_struct(grad_levels)
 
     per_image = tpi * 2048 * (n_in + 3 * nslab * NT + 1)
-    nb = max(1, min(B, ACT_BUDGET_BYTES // per_image))
+    nb = B if act16 is not None else max(1, min(B, ACT_BUDGET_BYTES // per_image))   # kept activations: all images in one go
     groups = B * ((tpi + 3) // 4)
     step = max(1, min(16, groups // 2048))          # dry-run sampling: every 16th tile group once there are plenty
     u_strat = _f32(rng.get("u_strat"))
@@ -457,12 +480,17 @@ def _render_backward16(net, o, levels, freq, phase, cam2world, rng, saved, grad_
         for b0 in range(0, B, nb):
             cnt = min(nb, B - b0)
             T = cnt * tpi
-            if act_T != T:
-                act = (torch.empty((T, n_in, 32, 32), **f16), torch.empty((nslab, T, NT, 32, 32), **f16),
-                       torch.empty((nslab, T, NT, 32, 32), **f16), torch.empty((nslab, T, NT, 32, 32), **f16),
-                       torch.zeros((T, 1, 32, 32), **f16))
-                act_T = T
-            a_feat, a_h, a_c, a_g, a_go = act
+            if act16 is not None:          # x0 / sin / cos were kept by the forward; only the gradient buffers are new
+                if act is None:
+                    act = (torch.empty((nslab, T, NT, 32, 32), **f16), torch.zeros((T, 1, 32, 32), **f16))
+                (a_feat, a_h, a_c), (a_g, a_go) = act16[pss], act
+            else:
+                if act_T != T:
+                    act = (torch.empty((T, n_in, 32, 32), **f16), torch.empty((nslab, T, NT, 32, 32), **f16),
+                           torch.empty((nslab, T, NT, 32, 32), **f16), torch.empty((nslab, T, NT, 32, 32), **f16),
+                           torch.zeros((T, 1, 32, 32), **f16))
+                    act_T = T
+                a_feat, a_h, a_c, a_g, a_go = act
             gmax = torch.zeros(nslab + 1, dtype=torch.int32, device=dev)
             # the head gradient's scale is known up front: |go'| <= |d loss / d rgb_sigma| (sigmoid' <= 1/4 only shrinks it)
             go_scale = _pow2_scales(g_out[b0:b0 + cnt].abs().amax().reshape(1).view(torch.int32))
@@ -475,7 +503,7 @@ def _render_backward16(net, o, levels, freq, phase, cam2world, rng, saved, grad_
                                                        L.ptr(a_c), L.ptr(a_g), L.ptr(a_go), L.ptr(scales_t), L.ptr(gmax), C.byref(gvs), _stream()),
                         "cnerf_field_backward16")
 
-            call(L.B16_STORE | L.B16_DRY, step, scales)
+            call((0 if act16 is not None else L.B16_STORE) | L.B16_DRY, step, scales)
             scales = torch.cat([_pow2_scales(gmax[:nslab]), go_scale])
             call(L.B16_CHAIN, 1, scales)
             if DEBUG_CAPTURE is not None:        # scripts/debug_b16.py: the chunk buffers of the first chunk of every pass
@@ -515,10 +543,10 @@ def _render_backward16(net, o, levels, freq, phase, cam2world, rng, saved, grad_
     return grad_levels, g_freq, g_phase, grads
 
 
-def render_backward(net, o, levels, freq, phase, cam2world, rng, saved, grad_pixels, grad_depth):
+def render_backward(net, o, levels, freq, phase, cam2world, rng, saved, grad_pixels, grad_depth, act16=None):
     """Gradients of one render w.r.t. (channel-last feature volumes, freq, phase, [field parameters])."""
     if backward_precision_of(net) == "fp16":
-        return _render_backward16(net, o, levels, freq, phase, cam2world, rng, saved, grad_pixels, grad_depth)
+        return _render_backward16(net, o, levels, freq, phase, cam2world, rng, saved, grad_pixels, grad_depth, act16)
     B, R, S, hier = o["B"], o["R"], o["S"], o["hier"]
     dev = cam2world.device
     # cfg: precision of the forward (the activation-storing re-run follows it); cfg32: the fp32 gradient chain
@@ -644,12 +672,16 @@ class RenderFunction(torch.autograd.Function):
         ph = phase.detach() if phase is not None else None
         need_grad = any(ctx.needs_input_grad)   # (grad mode is always off inside Function.forward)
         keys = SAVED_KEYS + (("coarse_points", "fine_points") if net.spec.layers[0] == "pfilm" else ())   # see _pfilm_backward
+        act16 = None
+        if need_grad and backward_precision_of(net) == "fp16" and precision_of(net) == "fp16x3":
+            act16 = resident_act16(net, levels, cam2world.shape[0], o["R"], o["S"], o["hier"], cam2world.device)
         pixels, depth, aux = render_forward(net, levels, fr, ph, cam2world, o["R"], o["fov"], o["ray_start"], o["ray_end"],
                                             o["S"], o["hier"], o["clamp_mode"], o["noise_std"], o["white_back"],
                                             o["last_back"], rng, want_aux=o["want_aux"], fvol_is_channel_last=True,
                                             field_events=o.get("field_events"),
-                                            aux_keys=keys if need_grad and not o["want_aux"] else None)
+                                            aux_keys=keys if need_grad and not o["want_aux"] else None, act16=act16)
         ctx.net, ctx.o, ctx.rng, ctx.n_vols = net, o, rng, n_vols
+        ctx.act16 = act16
         if need_grad:
             saved = [aux.get(k) for k in keys]
             if o["hier"] and rng.get("fine_z") is not None:
@@ -663,7 +695,9 @@ class RenderFunction(torch.autograd.Function):
         levels, fr, ph, cam2world, saved = ctx.saved
         g_levels, g_freq, g_phase, g_params = render_backward(ctx.net, ctx.o, levels, fr, ph, cam2world, ctx.rng, saved,
                                                               grad_pixels.contiguous(),
-                                                              grad_depth.contiguous() if grad_depth is not None else None)
+                                                              grad_depth.contiguous() if grad_depth is not None else None,
+                                                              act16=ctx.act16)
+        ctx.act16 = None
         g_vols = [g.permute(0, 4, 1, 2, 3) if cl else channel_first(g) for g, cl in zip(g_levels, ctx.vol_is_cl)]
         return (None, None, None, None, g_freq, g_phase, None, *g_vols, *g_params)
 

@@ -55,6 +55,10 @@ class GanTrainer:
             # arithmetic of the forward render (both the no-grad D-step images and the G-step forward): "fp32" or the
             # fp32-accurate split "fp16x3" (same parity gate, 2.7x faster)
             self.generator.siren.precision = metadata.get("render_precision", "fp32")
+            # arithmetic of the backward's gradient GEMMs: "fp32", or "fp16" (fp16 operands, fp32 sums -- the class of the
+            # reference's own autocast training, 2x faster; with render_precision "fp16x3" the forward's activations are kept
+            # for it instead of being re-computed)
+            self.generator.siren.backward_precision = metadata.get("backward_precision", "fp32")
         self.encoder = (modules["encoder"] if "encoder" in modules else UNet3D(**metadata["unet"])).to(device)
         if metadata.get("encoder_channels_last", False):     # NDHWC convolutions (MIOpen); off by default: measured below
             self.encoder = self.encoder.to(memory_format=torch.channels_last_3d)
