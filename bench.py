@@ -259,34 +259,46 @@ def fast_path(args, gen, fvol, glob, cam, meta, evs):
 def train_step_timing(args, gen, fvol, glob, cam, evs):
     """Secondary measurement: forward + backward of the render path (what the generator step of the GAN loop adds to the
     forward), nerf_noise 1.0 as at training step 0, gradients w.r.t. field parameters, FiLM mapping, feature volume and
-    global feature.  Priced against 3x the forward's algorithmic FLOPs (forward + two gradient GEMMs per layer)."""
+    global feature.  Two settings: everything exact fp32 (fp32 MFMA forward, chain and weight gradients), and the training
+    setting of the harness -- fp16x3 forward (fp32-accurate) whose activations are kept as fp16 tile blocks, gradient GEMMs
+    on the fp16 MFMA with fp32 sums (tests/test_gpu_parity.py::test_backward_half_precision).  Priced against 3x the
+    forward's algorithmic FLOPs (forward + two gradient GEMMs per layer)."""
     B, R, S = args.batch, args.img_size, args.num_steps
     meta = dict(clamp_mode="relu", nerf_noise=1.0, white_back=True, hierarchical_sample=True)
-    gen.train()
-    fv = fvol.detach().clone().requires_grad_(True)
-    gl = glob.detach().clone().requires_grad_(True)
-    reps = 3
-    torch.cuda.reset_peak_memory_stats()
-    times = []
-    try:
-        for i in range(reps + 1):
-            for p in gen.parameters():
-                p.grad = None
-            fv.grad = gl.grad = None
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            px, dp = gen(zin(gen, fv, gl), cam, R, FOV, RAY_START, RAY_END, S, **meta)
-            (px.square().mean() + dp.mean()).backward()
-            torch.cuda.synchronize()
-            if i > 0:
-                times.append(time.perf_counter() - t0)
-    finally:
-        gen.eval()
-    dt = float(np.median(times))
     flops = 3 * 2 * 2.0 * macs_per_point(32, args.hidden, len(gen.siren.spec.layers)) * B * R * R * S
-    return {"fwd_bwd_ms": dt * 1e3, "precision": gen.siren.precision, "images": B,
-            "achieved_tflops_over_3x_forward_flops": flops / dt / 1e12, "peak_mem_gib": torch.cuda.max_memory_allocated() / 2 ** 30,
-            "rays_per_s_fwd_bwd": B * R * R / dt}
+    out = {"images": B, "forward_ms_fp32": None}
+    keep = (gen.siren.precision, getattr(gen.siren, "backward_precision", "fp32"))
+    gen.train()
+    try:
+        for name, prec, bprec in (("fp32", "fp32", "fp32"), ("fp16x3_forward_fp16_backward", "fp16x3", "fp16")):
+            gen.siren.precision, gen.siren.backward_precision = prec, bprec
+            fv = fvol.detach().clone().requires_grad_(True)
+            gl = glob.detach().clone().requires_grad_(True)
+            torch.cuda.reset_peak_memory_stats()
+            times, fwd = [], []
+            for i in range(3):
+                for p in gen.parameters():
+                    p.grad = None
+                fv.grad = gl.grad = None
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                px, dp = gen(zin(gen, fv, gl), cam, R, FOV, RAY_START, RAY_END, S, **meta)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                (px.square().mean() + dp.mean()).backward()
+                torch.cuda.synchronize()
+                if i > 0:
+                    times.append(time.perf_counter() - t0)
+                    fwd.append(t1 - t0)
+            dt = float(np.median(times))
+            out[name] = {"fwd_bwd_ms": dt * 1e3, "forward_part_ms": float(np.median(fwd)) * 1e3, "rays_per_s_fwd_bwd": B * R * R / dt,
+                         "achieved_tflops_over_3x_forward_flops": flops / dt / 1e12, "peak_mem_gib": torch.cuda.max_memory_allocated() / 2 ** 30}
+            del fv, gl, px, dp
+            torch.cuda.empty_cache()
+    finally:
+        gen.siren.precision, gen.siren.backward_precision = keep
+        gen.eval()
+    return out
 
 
 def host_cores():

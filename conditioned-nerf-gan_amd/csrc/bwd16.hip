@@ -203,50 +203,88 @@ hipError_t launch_weight_grad16(int cnt, long long tiles_per_image, int n_rows, 
 //                             g_h  = W_m^T gp_m               (m = 0: the 32 channels of every input tile -> trilinear
 //                                                              scatter-add into the gradient volume, fp32 atomics)
 // Like the forward kernels, a wave owns a 32-point tile and the accumulator registers of one product are the B operand of
-// the next (channel = k).  All gradient VALUES live in fp32 registers in true units; fp16 appears only at the two conversion
+// the next (channel = k).  Gradient VALUES are handled in fp32 registers in true units; fp16 appears only at the two conversion
 // points, each with a power-of-two scale:
-//   * MFMA B operand: per POINT dynamic -- column j of the product depends on column j of B only, so every lane scales its
-//     own point by T_j = 2^(14 - exponent of its largest |gp|) and un-scales its accumulators by 1 / (s_m T_j) (s_m: the
-//     pre-scale of the packed W_m^T); tiny-gradient points keep all 11 bits, nothing overflows;
+//   * MFMA B operand: per POINT -- column j of a product depends on column j of B only, so every lane scales its own point.
+//     The scale of slab m is fixed BEFORE its values exist, from a bound: |gp_m| <= max|freq_m| * ||W_{m+1}||_1 * max_k|gp_{m+1}[k]|
+//     (the point's own largest operand of the product that produces g_h_m; ||W||_1 from the packing kernel, max|freq| per image
+//     when the FiLM vectors are staged): T = 2^14 / bound rounded down to a power of two, the accumulators are un-scaled by
+//     1 / (s_{m+1} T_{m+1}).  A floating-point format loses nothing to a loose bound except range at the bottom (the bound is
+//     ~20x the typical value: 4 of fp16's 30 binades), nothing overflows, tiny-gradient points keep all 11 bits -- and because
+//     the scale is known up front the epilogue of output tile t (cos, store, freq, convert) runs element by element in the
+//     shadow of the MFMAs of tile t + 1, as in field_h3.hip;
 //   * stored g16[m]: one scale S_m per slab for the whole call (the weight-gradient kernel sums over points on the k axis and
-//     cannot un-scale per point), chosen by the caller from the slab's largest |ga| as sampled by a DRY run of this kernel
-//     over every k-th tile group (no stores, atomicMax per slab); fmed3 clamps what a sample might have missed.
-// Weight units (two 32-row output tiles of a transposed matrix: 2 * KCH KiB) are streamed through a double buffer in LDS
-// by LDS-DMA and shared by the block's four waves, which work on four tiles of one image in lockstep (one barrier per unit)
-// -- the scheme of field_h3.hip.  cos(arg_m) of the next slab is fetched into registers under the MFMAs of the current one.
+//     cannot un-scale per point), chosen by the caller from the slab's largest |ga| as sampled by a DRY instantiation of this
+//     kernel over every k-th tile group (no stores, atomicMax per slab); fmed3 clamps what a sample might have missed.
+// Weight units (two 32-row output tiles of a transposed matrix: 2 * KCH KiB) stream through a three-slot ring in LDS by
+// LDS-DMA, shared by the block's four waves, which work on four tiles of one image in lockstep (one barrier per unit) -- the
+// scheme of field_h3.hip.  cos(arg) is fetched four output tiles ahead of the epilogue that consumes it.
 struct Chain16Args {
     FieldArgs f;              // geometry, tiles, freq, flags, layer kinds, gradient volumes, grad_out / saved_out
     const f16x8* units;       // transposed weight units in consumption order (pack_chain16)
     const f16x8* head_t;      // head^T fragments (NT x 64 lanes)
-    const float* winv;        // device: 1 / s_m per slab (index m), then the head's
+    const float* winv;        // device: 1 / s_m per slab (index m), then the head's; then ||W_m||_1 per slab and the head's
     const float* scales;      // device: per slab m {S_m, 1 / S_m}, then {S_go, 1 / S_go}
     const _Float16* cos16;    // TB16 (nslab, tiles, NT, 32, 32)
     _Float16* g16;            // TB16 (nslab, tiles, NT, 32, 32)
     _Float16* go16;           // TB16 (tiles, 1, 32, 32)
     unsigned int* gmax;       // dry run: per slab the bits of max |ga| (non-negative floats order like their bits), then max |go'|
     int nslab;
-    int dry;                  // 1: no stores, no scatter; only gmax
     int group_step;           // process every group_step-th tile group of a block's range (dry-run sampling)
 };
 
-__device__ __forceinline__ float pow2_below_2p14(float vmax) {
-    // T = 2^(14 - e) with vmax = m 2^e, m in [0.5, 1): vmax * T in [2^13, 2^14).  vmax == 0 (or denormal) -> 1.
-    const int e = (int)((__float_as_uint(vmax) >> 23) & 255u) - 126;
+__device__ __forceinline__ float pow2_scale_to_2p14(float bound) {
+    // T = 2^(14 - e) with bound = m 2^e, m in [0.5, 1): bound * T in [2^13, 2^14).  bound == 0 (or denormal / huge) -> 1.
+    const int e = (int)((__float_as_uint(bound) >> 23) & 255u) - 126;
     const int te = 127 + 14 - e;
-    return (vmax >= 1e-30f && te > 0 && te < 255) ? __uint_as_float((uint32_t)te << 23) : 1.0f;
+    return (bound >= 1e-30f && te > 0 && te < 255) ? __uint_as_float((uint32_t)te << 23) : 1.0f;
 }
 
-template <int NT>
+// per-tile state of the pipelined epilogue
+struct Epi16 {
+    float US, UT;             // accumulator -> stored scale (U * S_m) and -> operand scale (U * T)
+    const float* fr;          // LDS: freq of the slab (FiLM) or null (plain sine)
+    _Float16* gdst;           // g16 row of the lane's point, channel tile 0 of the slab (+ 4 h)
+    float vmax;               // running max |gp * T| of the point (this lane's channels)
+    float gmax;               // DRY: running max |ga * S|
+    float s4[4];              // the stored quad being assembled
+    float gp_even;            // the operand pair being assembled
+    bool live;
+};
+
+// one element r of output tile t: acc -> (store, operand fragment)
+template <bool DRY>
+__device__ __forceinline__ void epi16_element(const f32x16& acc, const f16x4* cosq, int t, int h, int r, Epi16& st, u32x4* frag_out) {
+    const int gq = r >> 2, e = r & 3;
+    const float ac = acc[r] * (float)cosq[gq][e];
+    const float gs = ac * st.US;                                             // ga * S_m
+    const float f = st.fr ? st.fr[32 * t + 8 * gq + 4 * h + e] : 1.0f;
+    const float gt = (ac * f) * st.UT;                                       // gp * T
+    st.vmax = fmaxf(st.vmax, fabsf(gt));
+    if (DRY) st.gmax = fmaxf(st.gmax, fabsf(gs));
+    else {
+        st.s4[e] = __builtin_amdgcn_fmed3f(gs, -65504.0f, 65504.0f);
+        if (e == 3 && st.live)
+            *reinterpret_cast<u32x2_*>(st.gdst + t * 1024 + 8 * gq) = u32x2_{pk_f16(st.s4[0], st.s4[1]), pk_f16(st.s4[2], st.s4[3])};
+    }
+    if ((r & 1) == 0) st.gp_even = gt;
+    else frag_out[2 * t + (r >> 3)][(r & 7) >> 1] = pk_f16(st.gp_even, gt);
+}
+
+template <int NT, bool DRY>
 __global__ __launch_bounds__(256) void chain16_kernel(Chain16Args A) {
     extern __shared__ __attribute__((aligned(16))) char smem_c[];
     const FieldArgs& a = A.f;
     constexpr int KCH = 2 * NT;                         // k-chunks of 16 per matrix row tile
     constexpr int UNIT_FR = 2 * KCH * 64;               // f16x8 fragments per weight unit (two output tiles)
     constexpr int PW = (2 * KCH) / 4;                   // 1-KiB pieces each wave copies per unit
+    constexpr int CD = NT < 4 ? NT : 4;                 // cos prefetch distance, in output tiles
+    constexpr int EPC = 16 / KCH > 0 ? 16 / KCH : 1;    // epilogue elements per k-chunk (KCH = 16: one)
     f16x8* lds_units = reinterpret_cast<f16x8*>(smem_c);                                   // 3 slots
     f16x8* lds_head = lds_units + 3 * UNIT_FR;                                              // NT * 64 fragments
     float* lds_freq = reinterpret_cast<float*>(lds_head + NT * 64);                        // film_stride floats (image of the block)
-    float* s_g = lds_freq + (a.film_stride > 0 ? a.film_stride : 4);                       // [4][32][33] scatter transpose
+    float* lds_fmax = lds_freq + (a.film_stride > 0 ? a.film_stride : 4);                  // per slab: max |freq| of the image (1: sine)
+    float* s_g = lds_fmax + CNERF_MAX_LAYERS;                                              // [4][32][33] scatter transpose
     int* s_base = reinterpret_cast<int*>(s_g + 4 * 32 * 33);                               // [4][32][8]
     float* s_w = reinterpret_cast<float*>(s_base + 4 * 32 * 8);                            // [4][32][8]
 
@@ -266,9 +304,7 @@ __global__ __launch_bounds__(256) void chain16_kernel(Chain16Args A) {
     const int n_l0_units = (a.n_in + 1) / 2;
     const int n_units = (A.nslab - 1) * (NT / 2) + n_l0_units;
     // Weight units travel through a ring of THREE LDS slots: unit k + 2 is requested when unit k starts, so a copy has two
-    // units' worth of MFMAs (2 x 1024 cycles at H = 256) to land -- with two slots (one unit ahead) every unit began with
-    // ~0.5 us of waiting for its copy (32 single-pass MFMAs per unit do not cover an L2 round trip; the forward's three-pass
-    // units do).
+    // units' worth of MFMAs to land.
     int dma_k = 0, dma_slot = 0, use_slot = 0;
     auto dma_next = [&]() {
         const f16x8* src = A.units + (size_t)dma_k * UNIT_FR + (size_t)wave_u * PW * 64 + lane;
@@ -280,16 +316,17 @@ __global__ __launch_bounds__(256) void chain16_kernel(Chain16Args A) {
         dma_k = dma_k + 1 == n_units ? 0 : dma_k + 1;
         dma_slot = dma_slot == 2 ? 0 : dma_slot + 1;
     };
-    // every wave, at the start of every unit: wait for this wave's share of the unit's copy -- vmcnt retires in order, so
-    // "all but the PW pieces of the NEXT unit's copy" -- then the barrier (everybody's share has landed, nobody still reads the
-    // slot about to be refilled), then request the unit after next.  `young`: behind the two copies in flight the wave has
-    // just issued the g16 stores of a slab and the cos loads of the next one (up to 64 operations, more than vmcnt can
-    // express on top of PW): waiting down to 63 outstanding retires both copies (requested long ago) and leaves those in
-    // flight under the MFMAs instead of stalling on them.
-    auto unit_begin = [&](bool young) -> const f16x8* {
-        if (young) __builtin_amdgcn_s_waitcnt(0xCF7F);          // vmcnt(63)
-        else __builtin_amdgcn_s_waitcnt(0x0F70 | PW);           // vmcnt(PW), PW <= 8
-        __syncthreads();
+    // every wave, at the start of every unit: this wave's share of the unit's copy (requested two units ago) must have landed.
+    // vmcnt retires in order.  `steady` (second and later units of a matrix): since that request the wave has issued, in
+    // order, the cos loads (4 per output tile) and g16 stores (up to 4 per tile) of two units and the NEXT unit's PW copy
+    // pieces -- at least 16 + PW operations whatever the mode (an idle wave and the dry run issue no stores), so waiting
+    // until at most 16 + PW are outstanding guarantees the copy and leaves the most recent stores / loads in flight under the
+    // MFMAs (a full drain here cost ~0.5 us per unit).  Elsewhere the operation count is irregular: full drain.
+    constexpr int STEADY_N = 16 + PW;
+    auto unit_begin = [&](bool steady) -> const f16x8* {
+        if (steady) __builtin_amdgcn_s_waitcnt(0x0F70 | (STEADY_N & 15) | ((STEADY_N >> 4) << 14));
+        else __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0)
+        __syncthreads();                                        // everybody's share has landed; nobody still reads the slot refilled next
         dma_next();
         const f16x8* u = lds_units + use_slot * UNIT_FR;
         use_slot = use_slot == 2 ? 0 : use_slot + 1;
@@ -301,6 +338,11 @@ __global__ __launch_bounds__(256) void chain16_kernel(Chain16Args A) {
     dma_next();
     int staged_b = -1;
     const float S_go = A.scales[2 * A.nslab], winv_head = A.winv[A.nslab];
+    const float* anorm = A.winv + A.nslab + 1;                  // ||W_m||_1 per slab, then the head's
+    if (!a.freq) {
+        for (int i = threadIdx.x; i < CNERF_MAX_LAYERS; i += 256) lds_fmax[i] = 1.0f;
+        __syncthreads();
+    }
 
     for (long long g = g_begin; g < g_end; g += g_stride) {
         const int b = (int)(g / G);
@@ -313,22 +355,33 @@ __global__ __launch_bounds__(256) void chain16_kernel(Chain16Args A) {
         const long long tile_T = (long long)b * a.tiles_per_image + (live ? tile_in_image : a.tiles_per_image - 1);
         const size_t slab16 = (size_t)a.total_tiles * NT * 1024;
         const size_t row16 = ((size_t)tile_T * NT * 32 + j) * 32;                           // element (T, t = 0, j, 0) inside a slab
-        if (b != staged_b && a.freq) {                                                     // block-uniform
+        if (b != staged_b && a.freq) {                                                     // block-uniform: FiLM vectors of the image
             __syncthreads();
             for (int i = threadIdx.x; i < a.film_stride; i += 256) lds_freq[i] = a.freq[(size_t)b * a.film_stride + i];
+            for (int i = threadIdx.x; i < CNERF_MAX_LAYERS; i += 256) lds_fmax[i] = 1.0f;
+            __syncthreads();
+            int fi = 0;
+            for (int m = 0; m < A.nslab; ++m) {
+                if (a.layer_kind[m] != CNERF_LAYER_FILM) continue;
+                float v = 0.0f;
+                for (int i = threadIdx.x; i < NT * 32; i += 256) v = fmaxf(v, fabsf(lds_freq[fi * NT * 32 + i]));
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d, WAVE));
+                if (lane == 0) atomicMax(reinterpret_cast<unsigned int*>(lds_fmax + m), __float_as_uint(v));   // (>= 1 already there: FiLM freq ~ 30)
+                ++fi;
+            }
             staged_b = b;
             __syncthreads();
         }
-        // cos of the last slab: in flight under the head product
-        f16x4 cosr[NT * 4];         // (indexed as fp16 elements: hipcc 7.2 mis-extracts bit_cast<f16x2>(u32x2[1]) as element 0)
-        auto fetch_cos = [&](int m) {
-            const _Float16* src = A.cos16 + (size_t)m * slab16 + row16 + 4 * h;
+        // cos(arg) ring: CD output tiles ahead of their epilogue, over the linear sequence (slab last .. 0) x (tile 0 .. NT-1)
+        f16x4 cosr[CD][4];
+        auto fetch_cos = [&](int m, int t, int slot) {
+            const _Float16* src = A.cos16 + (size_t)m * slab16 + row16 + 4 * h + t * 1024;
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int gq = 0; gq < 4; ++gq) cosr[4 * t + gq] = *reinterpret_cast<const f16x4*>(src + t * 1024 + 8 * gq);
+            for (int gq = 0; gq < 4; ++gq) cosr[slot][gq] = *reinterpret_cast<const f16x4*>(src + 8 * gq);
         };
-        fetch_cos(A.nslab - 1);
+#pragma unroll
+        for (int t = 0; t < CD; ++t) fetch_cos(A.nslab - 1, t, t);
 
         // ---- head backward -------------------------------------------------------------------------------------------
         f32x4 go = *reinterpret_cast<const f32x4*>(a.grad_out + gpt * 4);
@@ -345,17 +398,58 @@ __global__ __launch_bounds__(256) void chain16_kernel(Chain16Args A) {
             gs[i] = __builtin_amdgcn_fmed3f(go[i] * S_go, -60000.0f, 60000.0f);
             gl[i] = gs[i] - (float)(_Float16)gs[i];
         }
-        if (A.dry) {
-            float m4 = fmaxf(fmaxf(fabsf(go[0]), fabsf(go[1])), fmaxf(fabsf(go[2]), fabsf(go[3])));
+        const float gomax = fmaxf(fmaxf(fabsf(go[0]), fabsf(go[1])), fmaxf(fabsf(go[2]), fabsf(go[3])));
+        if (DRY) {
+            float m4 = gomax;
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) m4 = fmaxf(m4, __shfl_xor(m4, d, WAVE));
             if (lane == 0) atomicMax(A.gmax + A.nslab, __float_as_uint(m4));
         } else if (live && h == 0) {                    // row j of the tile's single channel block: channels 0..3 (the rest stays zero)
             *reinterpret_cast<u32x2_*>(A.go16 + ((size_t)tile_T * 32 + j) * 32) = u32x2_{pk_f16(gs[0], gs[1]), pk_f16(gs[2], gs[3])};
         }
-        f32x16 acc[NT];
+
+        int film_idx = 0;
+        for (int l = 0; l < A.nslab; ++l) film_idx += (a.layer_kind[l] == CNERF_LAYER_FILM);
+        // B operands: the one being consumed and the one being produced; copied over after every slab (64 moves: swapping
+        // pointers instead sends both arrays to scratch memory -- the register indices must be static)
+        u32x4 frag_in[KCH], frag_out[KCH];
+
+        // epilogue state of the slab whose g_h is being produced
+        Epi16 st;
+        st.live = live;
+        auto begin_slab = [&](int m, float U, float bound_gp) -> float {          // returns T
+            const bool film = a.layer_kind[m] == CNERF_LAYER_FILM;
+            if (film) --film_idx;
+            st.fr = film ? lds_freq + (size_t)film_idx * (NT * 32) : nullptr;
+            const float T = pow2_scale_to_2p14(bound_gp);
+            st.US = U * A.scales[2 * m];
+            st.UT = U * T;
+            st.gdst = A.g16 + (size_t)m * slab16 + row16 + 4 * h;
+            st.vmax = 0.0f;
+            st.gmax = 0.0f;
+            return T;
+        };
+        auto end_slab = [&](int m, float T) -> float {                             // returns the point's max |gp| in true units
+            if (DRY) {
+                float gm = st.gmax / A.scales[2 * m];
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) gm = fmaxf(gm, __shfl_xor(gm, d, WAVE));
+                if (lane == 0) atomicMax(A.gmax + m, __float_as_uint(gm));
+            }
+            const float v = fmaxf(st.vmax, __shfl_xor(st.vmax, 32, WAVE));     // the two lane halves of a point
+            return v / T;
+        };
+        // linear (slab, tile) position -> the cos prefetch CD tiles ahead
+        auto prefetch_after = [&](int m, int t) {
+            const int tn = t + CD;
+            if (tn < NT) fetch_cos(m, tn, t % CD);
+            else if (m > 0) fetch_cos(m - 1, tn - NT, t % CD);
+        };
+
+        // ---- head product: g_h of the last slab, epilogue right behind each tile (2 MFMAs per tile: nothing to hide under) --
+        int m = A.nslab - 1;
+        float T = begin_slab(m, winv_head / S_go, lds_fmax[m] * anorm[A.nslab] * gomax);
         {
-            // B fragment: element jj of lane half h is k = 8 h + jj; the head has 4 outputs (k < 4): half 0, elements 0..3
             const u32x4 bh = h == 0 ? u32x4{pk_f16(gs[0], gs[1]), pk_f16(gs[2], gs[3]), 0u, 0u} : u32x4{0u, 0u, 0u, 0u};
             const u32x4 bl = h == 0 ? u32x4{pk_f16(gl[0], gl[1]), pk_f16(gl[2], gl[3]), 0u, 0u} : u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
@@ -366,87 +460,55 @@ __global__ __launch_bounds__(256) void chain16_kernel(Chain16Args A) {
                 const f16x8 aw = lds_head[t * 64 + lane];
                 z = __builtin_amdgcn_mfma_f32_32x32x16_f16(aw, __builtin_bit_cast(f16x8, bl), z, 0, 0, 0);
                 z = __builtin_amdgcn_mfma_f32_32x32x16_f16(aw, __builtin_bit_cast(f16x8, bh), z, 0, 0, 0);
-                acc[t] = z;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) epi16_element<DRY>(z, cosr[t % CD], t, h, r, st, frag_out);
+                prefetch_after(m, t);
             }
         }
-        float U = winv_head / S_go;                      // accumulators -> true units
-
-        // ---- slabs, last to first ---------------------------------------------------------------------------------------
-        int film_idx = 0;
-        for (int l = 0; l < a.L; ++l) film_idx += (a.layer_kind[l] == CNERF_LAYER_FILM);
-        u32x4 frag[KCH];                                // B operand of the next product: k-chunk c = channels 16 c .. 16 c + 15
-        for (int m = A.nslab - 1; m >= 0; --m) {
-            const bool film = a.layer_kind[m] == CNERF_LAYER_FILM;
-            if (film) --film_idx;
-            const float* fr = film ? lds_freq + (size_t)film_idx * (NT * 32) : nullptr;
-            const float S_m = A.scales[2 * m];
-            // pass 1: ga = g_h cos (true units, kept in the accumulators), its store, the point's largest |gp|
-            float vmax = 0.0f, gmax_l = 0.0f;
-            _Float16* gdst = A.g16 + (size_t)m * slab16 + row16 + 4 * h;
+        float gpmax = end_slab(m, T);
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
+        for (int c = 0; c < KCH; ++c) frag_in[c] = frag_out[c];
+        // ---- slabs last-1 .. 0: g_h = W_{m+1}^T gp_{m+1}, epilogue of tile t under the MFMAs of tile t + 1 --------------------
+        for (m = A.nslab - 2; m >= 0; --m) {
+            const float Tn = begin_slab(m, A.winv[m + 1] / T, lds_fmax[m] * anorm[m + 1] * gpmax);
+            f32x16 acc_prev;
 #pragma unroll
-                for (int gq = 0; gq < 4; ++gq) {
-                    const f16x4 cw = cosr[4 * t + gq];
-                    const float cv[4] = {(float)cw[0], (float)cw[1], (float)cw[2], (float)cw[3]};
-                    float ga[4];
+            for (int u = 0; u < NT / 2; ++u) {
+                const f16x8* unit = unit_begin(u >= 1);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        ga[e] = acc[t][4 * gq + e] * U * cv[e];
-                        acc[t][4 * gq + e] = ga[e];
-                        const float f = film ? fr[32 * t + 8 * gq + 4 * h + e] : 1.0f;
-                        vmax = fmaxf(vmax, fabsf(ga[e] * f));
-                        gmax_l = fmaxf(gmax_l, fabsf(ga[e]));
+                for (int sub = 0; sub < 2; ++sub) {
+                    const int t = 2 * u + sub;
+                    const f16x8* tile = unit + sub * KCH * 64 + lane;
+                    f32x16 z;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) z[r] = 0.0f;
+                    f16x8 ring[2] = {tile[0], tile[64]};
+#pragma unroll
+                    for (int c = 0; c < KCH; ++c) {
+                        const f16x8 aw = ring[c & 1];
+                        if (c + 2 < KCH) ring[c & 1] = tile[(c + 2) * 64];
+                        z = __builtin_amdgcn_mfma_f32_32x32x16_f16(aw, __builtin_bit_cast(f16x8, frag_in[c]), z, 0, 0, 0);
+                        if (t > 0) {
+#pragma unroll
+                            for (int q = 0; q < EPC; ++q) epi16_element<DRY>(acc_prev, cosr[(t - 1) % CD], t - 1, h, c * EPC + q, st, frag_out);
+                        }
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 9 * EPC, 0);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
-#ifdef C16_NOSTORE
-                    if (false) {
-#else
-                    if (!A.dry && live) {
-#endif
-                        float s4[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) s4[e] = __builtin_amdgcn_fmed3f(ga[e] * S_m, -65504.0f, 65504.0f);
-                        *reinterpret_cast<u32x2_*>(gdst + t * 1024 + 8 * gq) = u32x2_{pk_f16(s4[0], s4[1]), pk_f16(s4[2], s4[3])};
-                    }
+                    if (t > 0) prefetch_after(m, t - 1);
+                    acc_prev = z;
                 }
             }
-            if (A.dry) {
 #pragma unroll
-                for (int d = 32; d >= 1; d >>= 1) gmax_l = fmaxf(gmax_l, __shfl_xor(gmax_l, d, WAVE));
-                if (lane == 0) atomicMax(A.gmax + m, __float_as_uint(gmax_l));
-            }
-            if (m > 0) fetch_cos(m - 1);                 // lands under the MFMAs below
-            vmax = fmaxf(vmax, __shfl_xor(vmax, 32, WAVE));   // the two lane halves of a point share its scale
-            const float T = pow2_below_2p14(vmax);
-            // pass 2: the fp16 B operand, gp * T
+            for (int r = 0; r < 16; ++r) epi16_element<DRY>(acc_prev, cosr[(NT - 1) % CD], NT - 1, h, r, st, frag_out);
+            prefetch_after(m, NT - 1);
+            gpmax = end_slab(m, Tn);
+            T = Tn;
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; r += 2) {
-                    const int ch = 32 * t + 8 * (r >> 2) + 4 * h + (r & 3);
-                    const float f0 = film ? fr[ch] : 1.0f, f1 = film ? fr[ch + 1] : 1.0f;
-                    frag[2 * t + (r >> 3)][(r & 7) >> 1] = pk_f16(acc[t][r] * f0 * T, acc[t][r + 1] * f1 * T);
-                }
-            const float winv_m = A.winv[m];
-            U = winv_m / T;
-            if (m > 0) {
-                // g_h of slab m-1 = W_m^T gp_m: NT output tiles, two per weight unit
-#pragma unroll
-                for (int u = 0; u < NT / 2; ++u) {
-                    const f16x8* unit = unit_begin(u == 0);
-#pragma unroll
-                    for (int sub = 0; sub < 2; ++sub) {
-                        f32x16 z;
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) z[r] = 0.0f;
-#pragma unroll
-                        for (int c = 0; c < KCH; ++c)
-                            z = __builtin_amdgcn_mfma_f32_32x32x16_f16(unit[(sub * KCH + c) * 64 + lane], __builtin_bit_cast(f16x8, frag[c]), z, 0, 0, 0);
-                        acc[2 * u + sub] = z;
-                    }
-                }
-            }
+            for (int c = 0; c < KCH; ++c) frag_in[c] = frag_out[c];
         }
+        const float U0 = A.winv[0] / T;                  // accumulators of the layer-0 products -> true units
         // ---- layer 0: one 32-channel gradient tile per input tile; feature tiles are scattered, the xyz tile is dropped ----------
         float px, py, pz;
         tile_point(a, b, nn, valid, h, false, px, py, pz);
@@ -455,25 +517,25 @@ __global__ __launch_bounds__(256) void chain16_kernel(Chain16Args A) {
         int* sb = s_base + wave * 32 * 8;
         float* sw = s_w + wave * 32 * 8;
         for (int u = 0; u < n_l0_units; ++u) {
-            const f16x8* unit = unit_begin(u == 0 && A.nslab > 0);
+            const f16x8* unit = unit_begin(false);
             for (int sub = 0; sub < 2; ++sub) {
                 const int tk = 2 * u + sub;
                 if (tk >= a.n_in) break;
                 const int lvl = a.in_level[tk];
-                if (lvl < 0 || A.dry) continue;                              // no gradient flows to the sample positions
+                if (lvl < 0 || DRY) continue;                                // no gradient flows to the sample positions
                 f32x16 z;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) z[r] = 0.0f;
 #pragma unroll
                 for (int c = 0; c < KCH; ++c)
-                    z = __builtin_amdgcn_mfma_f32_32x32x16_f16(unit[(sub * KCH + c) * 64 + lane], __builtin_bit_cast(f16x8, frag[c]), z, 0, 0, 0);
+                    z = __builtin_amdgcn_mfma_f32_32x32x16_f16(unit[(sub * KCH + c) * 64 + lane], __builtin_bit_cast(f16x8, frag_in[c]), z, 0, 0, 0);
                 const int V = a.lvl_V[lvl], C = a.lvl_C[lvl];
                 Corner8 cr;
                 trilinear_corners(px, py, pz, a.half_voxel, V, cr);
 #pragma unroll
                 for (int gq = 0; gq < 4; ++gq)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) sg[j * 33 + 8 * gq + 4 * h + e] = z[4 * gq + e] * U;
+                    for (int e = 0; e < 4; ++e) sg[j * 33 + 8 * gq + 4 * h + e] = z[4 * gq + e] * U0;
                 if (h == 0) {
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
@@ -501,7 +563,7 @@ __global__ __launch_bounds__(256) void chain16_kernel(Chain16Args A) {
         }
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);
-    __syncthreads();                                    // drain the copy issued for a unit this block does not consume
+    __syncthreads();                                    // drain the copies issued for units this block does not consume
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -561,6 +623,24 @@ __global__ void pack_head_t16_kernel(const float* __restrict__ w, int H, const u
     }
 }
 
+// ||W||_1 = max over columns r of sum_k |W[k][r]| (W row-major (n_rows, n_cols)): the bound on |W^T x|_inf / |x|_inf the chain
+// kernel scales its operands by.  One thread per column, atomicMax of the bits into *slot (zeroed by the caller).
+__global__ void col_abs_sum_max_kernel(const float* __restrict__ w, int n_rows, int n_cols, uint32_t* slot) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    float s = 0.0f;
+    if (r < n_cols)
+        for (int k = 0; k < n_rows; ++k) s += fabsf(w[(size_t)k * n_cols + r]);
+#pragma unroll
+    for (int d = WAVE / 2; d >= 1; d >>= 1) s = fmaxf(s, __shfl_xor(s, d, WAVE));
+    if ((threadIdx.x & 63) == 0 && s == s) atomicMax(slot, __float_as_uint(s));
+}
+
+hipError_t launch_col_abs_sum_max(const float* w, int n_rows, int n_cols, float* slot, hipStream_t stream) {
+    if (hipError_t e = hipMemsetAsync(slot, 0, sizeof(float), stream)) return e;
+    hipLaunchKernelGGL(col_abs_sum_max_kernel, dim3((unsigned)((n_cols + 255) / 256)), dim3(256), 0, stream, w, n_rows, n_cols, (uint32_t*)slot);
+    return hipGetLastError();
+}
+
 // One transposed matrix: OT output tiles (padded to even), KCH = rows of W / 16 chunks.  scratch: one uint32 per call.
 hipError_t launch_pack_t16(const float* w, int n_rows_w, int n_cols_w, int n_cols_real, int OT_padded, void* dst, float* winv_slot, uint32_t* wmax_slot,
                            hipStream_t stream) {
@@ -597,7 +677,7 @@ struct Chain16Launch {
     int nslab, dry, group_step;
 };
 
-template <int NT>
+template <int NT, bool DRY>
 static hipError_t launch_chain16_nt(const FieldArgs& f, const Chain16Launch& c, hipStream_t stream) {
     Chain16Args A;
     A.f = f;
@@ -610,20 +690,19 @@ static hipError_t launch_chain16_nt(const FieldArgs& f, const Chain16Launch& c, 
     A.go16 = (_Float16*)c.go16;
     A.gmax = c.gmax;
     A.nslab = c.nslab;
-    A.dry = c.dry;
     A.group_step = c.group_step < 1 ? 1 : c.group_step;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) != hipSuccess) dev = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
     const size_t lds_bytes = (size_t)3 * (2 * 2 * NT * 64) * 16 + (size_t)NT * 64 * 16 + (size_t)(f.film_stride > 0 ? f.film_stride : 4) * 4 +
-                             (size_t)4 * 32 * 33 * 4 + (size_t)2 * 4 * 32 * 8 * 4;
+                             (size_t)CNERF_MAX_LAYERS * 4 + (size_t)4 * 32 * 33 * 4 + (size_t)2 * 4 * 32 * 8 * 4;
     if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
-    if (hipError_t e = hipFuncSetAttribute((const void*)chain16_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)) return e;
+    if (hipError_t e = hipFuncSetAttribute((const void*)chain16_kernel<NT, DRY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)) return e;
     const long long want = (f.total_tiles / f.tiles_per_image) * ((f.tiles_per_image + 3) / 4);
     int blocks = (int)(want < cus ? want : cus);
     if (blocks < 8) blocks = 8;
     blocks = (blocks + 7) / 8 * 8;
-    hipLaunchKernelGGL((chain16_kernel<NT>), dim3(blocks), dim3(256), lds_bytes, stream, A);
+    hipLaunchKernelGGL((chain16_kernel<NT, DRY>), dim3(blocks), dim3(256), lds_bytes, stream, A);
     return hipGetLastError();
 }
 
@@ -631,9 +710,9 @@ hipError_t launch_chain16(const FieldArgs& f, int H, const void* units, const vo
                           void* g16, void* go16, unsigned int* gmax, int nslab, int dry, int group_step, hipStream_t stream) {
     const Chain16Launch c{units, head_t, winv, scales, cos16, g16, go16, gmax, nslab, dry, group_step};
     switch (H / 32) {
-        case 2: return launch_chain16_nt<2>(f, c, stream);
-        case 4: return launch_chain16_nt<4>(f, c, stream);
-        case 8: return launch_chain16_nt<8>(f, c, stream);
+        case 2: return dry ? launch_chain16_nt<2, true>(f, c, stream) : launch_chain16_nt<2, false>(f, c, stream);
+        case 4: return dry ? launch_chain16_nt<4, true>(f, c, stream) : launch_chain16_nt<4, false>(f, c, stream);
+        case 8: return dry ? launch_chain16_nt<8, true>(f, c, stream) : launch_chain16_nt<8, false>(f, c, stream);
         default: return hipErrorInvalidValue;
     }
 }

@@ -620,7 +620,8 @@ int cnerf_weight_grad16(int32_t n_images, int64_t tiles_per_image, int32_t n_row
 
 namespace {
 // packed16 layout: [transposed units of matrices n_mats-1 .. 1, then layer 0 (output tiles padded to even)][head^T: NT fragments
-// x 64 lanes][winv: n_mats + 1 floats][max|W| scratch: n_mats + 1 uint32], each section 256-byte aligned
+// x 64 lanes][winv: n_mats + 1 floats, then ||W||_1: n_mats + 1 floats][max|W| scratch: n_mats + 1 uint32], each section
+// 256-byte aligned
 struct Chain16Layout {
     size_t units_bytes, head_off, winv_off, wmax_off, total;
     int n_mats, n_in, k0, ot0;
@@ -638,7 +639,7 @@ int chain16_layout(const cnerf_cfg* c, Chain16Layout& l) {
     l.units_bytes = ((size_t)(c->L - 1) * NT + l.ot0) * KCH * frag;
     l.head_off = align256(l.units_bytes);
     l.winv_off = l.head_off + align256(NT * frag);
-    l.wmax_off = l.winv_off + align256((size_t)(c->L + 1) * sizeof(float));
+    l.wmax_off = l.winv_off + align256((size_t)2 * (c->L + 1) * sizeof(float));
     l.total = l.wmax_off + align256((size_t)(c->L + 1) * sizeof(uint32_t));
     return CNERF_OK;
 }
@@ -674,6 +675,10 @@ int cnerf_pack_field_chain16(const cnerf_cfg* cfg, const cnerf_field_params* p, 
     if (!p->w[0]) return fail(CNERF_EINVAL, "pack_field_chain16: layer 0 weight is NULL");
     if (hipError_t e = launch_pack_t16(p->w[0], H, l.k0, l.k0, l.ot0, dst, winv + 0, wmax + 0, stream)) return hip_fail(e, "pack_t16");
     if (hipError_t e = launch_pack_head_t16(p->w_final, H, base + l.head_off, winv + cfg->L, wmax + cfg->L, stream)) return hip_fail(e, "pack_head_t16");
+    float* anorm = winv + cfg->L + 1;                  // ||W_m||_1 per matrix, then the head's (4 x H: max over channels of the 4-term sum)
+    for (int m = 0; m < cfg->L; ++m)
+        if (hipError_t e = launch_col_abs_sum_max(p->w[m], H, m == 0 ? l.k0 : H, anorm + m, stream)) return hip_fail(e, "col_abs_sum_max");
+    if (hipError_t e = launch_col_abs_sum_max(p->w_final, 4, H, anorm + cfg->L, stream)) return hip_fail(e, "col_abs_sum_max");
     return CNERF_OK;
 }
 

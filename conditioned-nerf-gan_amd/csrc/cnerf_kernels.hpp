@@ -157,6 +157,7 @@ hipError_t launch_weight_grad(int cnt, long long npi, int H, int K, const float*
 // bwd16.hip
 hipError_t launch_pack_t16(const float* w, int n_rows_w, int n_cols_w, int n_cols_real, int OT_padded, void* dst, float* winv_slot, uint32_t* wmax_slot,
                            hipStream_t stream);
+hipError_t launch_col_abs_sum_max(const float* w, int n_rows, int n_cols, float* slot, hipStream_t stream);
 hipError_t launch_pack_head_t16(const float* w, int H, void* dst, float* winv_slot, uint32_t* wmax_slot, hipStream_t stream);
 hipError_t launch_chain16(const FieldArgs& f, int H, const void* units, const void* head_t, const float* winv, const float* scales, const void* cos16,
                           void* g16, void* go16, unsigned int* gmax, int nslab, int dry, int group_step, hipStream_t stream);
