@@ -218,14 +218,14 @@ hipError_t launch_weight_grad16(int cnt, long long tiles_per_image, int n_rows, 
 //     kernel over every k-th tile group (no stores, atomicMax per slab); fmed3 clamps what a sample might have missed.
 // Weight units (two 32-row output tiles of a transposed matrix: 2 * KCH KiB) stream through a three-slot ring in LDS by
 // LDS-DMA, shared by the block's four waves, which work on four tiles of one image in lockstep (one barrier per unit) -- the
-// scheme of field_h3.hip.  cos(arg) is fetched four output tiles ahead of the epilogue that consumes it.
+// scheme of field_h3.hip.  cos(arg) is fetched a slab's worth of output tiles ahead of the epilogue that consumes it.
 struct Chain16Args {
     FieldArgs f;              // geometry, tiles, freq, flags, layer kinds, gradient volumes, grad_out / saved_out
     const f16x8* units;       // transposed weight units in consumption order (pack_chain16)
     const f16x8* head_t;      // head^T fragments (NT x 64 lanes)
     const float* winv;        // device: 1 / s_m per slab (index m), then the head's; then ||W_m||_1 per slab and the head's
     const float* scales;      // device: per slab m {S_m, 1 / S_m}, then {S_go, 1 / S_go}
-    const _Float16* cos16;    // TB16 (nslab, tiles, NT, 32, 32)
+    const _Float16* cos16;    // COS16 (nslab, tiles, NT, 4, 64, 4): fragment-major, bwd16.hpp
     _Float16* g16;            // TB16 (nslab, tiles, NT, 32, 32)
     _Float16* go16;           // TB16 (tiles, 1, 32, 32)
     unsigned int* gmax;       // dry run: per slab the bits of max |ga| (non-negative floats order like their bits), then max |go'|
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256) void chain16_kernel(Chain16Args A) {
     constexpr int KCH = 2 * NT;                         // k-chunks of 16 per matrix row tile
     constexpr int UNIT_FR = 2 * KCH * 64;               // f16x8 fragments per weight unit (two output tiles)
     constexpr int PW = (2 * KCH) / 4;                   // 1-KiB pieces each wave copies per unit
-    constexpr int CD = NT < 4 ? NT : 4;                 // cos prefetch distance, in output tiles
+    constexpr int CD = NT;                              // cos prefetch distance, in output tiles: a whole slab ahead
     constexpr int EPC = 16 / KCH > 0 ? 16 / KCH : 1;    // epilogue elements per k-chunk (KCH = 16: one)
     f16x8* lds_units = reinterpret_cast<f16x8*>(smem_c);                                   // 3 slots
     f16x8* lds_head = lds_units + 3 * UNIT_FR;                                              // NT * 64 fragments
@@ -376,9 +376,9 @@ __global__ __launch_bounds__(256) void chain16_kernel(Chain16Args A) {
         // cos(arg) ring: CD output tiles ahead of their epilogue, over the linear sequence (slab last .. 0) x (tile 0 .. NT-1)
         f16x4 cosr[CD][4];
         auto fetch_cos = [&](int m, int t, int slot) {
-            const _Float16* src = A.cos16 + (size_t)m * slab16 + row16 + 4 * h + t * 1024;
+            const _Float16* src = A.cos16 + (size_t)m * slab16 + (((size_t)tile_T * NT + t) * 256 + lane) * 4;      // COS16 layout (bwd16.hpp)
 #pragma unroll
-            for (int gq = 0; gq < 4; ++gq) cosr[slot][gq] = *reinterpret_cast<const f16x4*>(src + 8 * gq);
+            for (int gq = 0; gq < 4; ++gq) cosr[slot][gq] = *reinterpret_cast<const f16x4*>(src + gq * 256);
         };
 #pragma unroll
         for (int t = 0; t < CD; ++t) fetch_cos(A.nslab - 1, t, t);

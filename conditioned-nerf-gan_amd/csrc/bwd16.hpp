@@ -9,6 +9,11 @@
 // a 2-KiB block that four such instructions complete; the weight-gradient kernel copies a whole tile (all channel tiles of
 // 32 points, contiguous) into LDS with linear LDS-DMA and reads MFMA operands out of the 64-byte rows with
 // ds_read_b64_tr_b16, conflict-free (bank = 16 j + c / 2 over the 4 rows x 32 channels a half-wave reads).
+//
+// "COS16": cos(arg) of every slab travels from the storing forward to the chain kernel only, lane for lane (lane (j, h) of the
+// wave that owns tile T holds channels 32 t + 8 g + 4 h + e of point j), so it is stored fragment-major -- same size, but every
+// wave instruction moves 512 contiguous bytes instead of 16 bytes in each of 32 rows:
+//     element (slab m, tile T, channel tile t, quad g, lane, e) -> fp16 index ((((m * tiles + T) * NT + t) * 4 + g) * 64 + lane) * 4 + e
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

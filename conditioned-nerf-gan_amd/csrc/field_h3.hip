@@ -198,7 +198,9 @@ __device__ __forceinline__ void film_split_pair(const f32x16& acc, float inv_s, 
         } else if (st.live) {        // four consecutive channels of the lane's point: one 8-byte store per matrix
             const int off = t * 1024 + 8 * (r >> 2) + 4 * h;
             *reinterpret_cast<u32x2_*>(st.blk_h + off) = u32x2_{pk_f16(st.ks[0], st.ks[1]), pk_f16(v0, v1)};
-            *reinterpret_cast<u32x2_*>(st.blk_c + off) = u32x2_{pk_f16(st.kc[0], st.kc[1]), pk_f16(c0, c1)};
+            // cos is read back only by the chain kernel, lane for lane: fragment-major (bwd16.hpp "COS16"), 512 contiguous bytes
+            // per wave instruction
+            *reinterpret_cast<u32x2_*>(st.blk_c + (t * 4 + (r >> 2)) * 256) = u32x2_{pk_f16(st.kc[0], st.kc[1]), pk_f16(c0, c1)};
         }
     } else {
         v0 = sin_2pi_reduced_hw(a0);
@@ -476,7 +478,7 @@ __global__ __launch_bounds__(256) void field_h3_kernel(FieldArgs a) {
         const size_t slab16 = (size_t)a.total_tiles * NT * 1024;      // fp16 elements per slab (a.total_tiles = tiles of the chunk)
         st.live = tile_in_image < a.tiles_per_image;
         st.blk_h = STORE == STORE_TB16 ? reinterpret_cast<_Float16*>(a.act_h) + ((size_t)tile_T * NT * 32 + j) * 32 : nullptr;
-        st.blk_c = STORE == STORE_TB16 ? reinterpret_cast<_Float16*>(a.act_c) + ((size_t)tile_T * NT * 32 + j) * 32 : nullptr;
+        st.blk_c = STORE == STORE_TB16 ? reinterpret_cast<_Float16*>(a.act_c) + ((size_t)tile_T * NT * 256 + lane) * 4 : nullptr;
         // ---- layer 0: one weight unit per input tile ------------------------------------------------------------------
         {
             f32x16 acc0[NT];

@@ -284,8 +284,9 @@ int cnerf_pack_field_chain16(const cnerf_cfg* cfg, const cnerf_field_params* par
 
 /* Twin of cnerf_field_backward (same pass / image-range / per-image-input conventions) for the half-precision path.
  *   cfg->precision must be CNERF_PREC_FP16X3 and `packed` its forward layout (the re-run is that kernel);
- *   act_feat16 (T, n_in, 32, 32), act_h16 / act_c16 / act_g16 (n_mats, T, H/32, 32, 32), act_go16 (T, 1, 32, 32; ZERO it
- *   first: only channels 0..3 are written): fp16 TB16 chunk buffers, T = n_images * ceil(R*R*S / 32);
+ *   act_feat16 (T, n_in, 32, 32), act_h16 / act_g16 (n_mats, T, H/32, 32, 32), act_go16 (T, 1, 32, 32; ZERO it first: only
+ *   channels 0..3 are written): fp16 TB16 chunk buffers, T = n_images * ceil(R*R*S / 32); act_c16: the same number of bytes as
+ *   act_h16, private to the storing forward and the chain (fragment-major, csrc/bwd16.hpp "COS16");
  *   scales (DEVICE, 2 * (n_mats + 1) floats): per matrix m {S_m, 1 / S_m} = power-of-two scale of act_g16[m], then
  *   {S_go, 1 / S_go} of act_go16 -- the caller derives them from gmax;  gmax (DEVICE, n_mats + 1 uint32, zero it first): bit
  *   patterns of the sampled maxima written by a CNERF_B16_DRY call (max |d/d arg_m| per matrix, then max |go'|).

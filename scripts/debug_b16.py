@@ -39,7 +39,7 @@ for pss in (0, 1):
     print(f"pass {pss}: npi {npi} tpi {tpi} cnt {cnt}; scales {a['scales'].tolist()}; gmax {a['gmax'].view(torch.float32).tolist()}")
     print("  feat", rel(untb(a["feat"], n)[rows][:, :b["feat"].shape[1]], b["feat"]))
     for l in range(b["h"].shape[0]):
-        print(f"  slab {l}: sin {rel(untb(a['h'][l], n)[rows], b['h'][l]):.2e} cos {rel(untb(a['c'][l], n)[rows], b['c'][l]):.2e} "
+        print(f"  slab {l}: sin {rel(untb(a['h'][l], n)[rows], b['h'][l]):.2e} (cos: fragment-major, private to the chain) "
               f"g {rel(untb(a['g'][l], n)[rows] * a['scales'][2 * l + 1], b['g'][l]):.2e}  |g|max {b['g'][l].abs().max().item():.3e}")
     nsl = b["h"].shape[0]
     print("  go", rel(untb(a["go"], n)[rows][:, :4] * a["scales"][2 * nsl + 1], b["go"]), " |go|max", b["go"].abs().max().item())
