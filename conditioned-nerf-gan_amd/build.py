@@ -24,12 +24,14 @@ def build_library(force=False, verbose=False, extra_flags=()):
     extra_flags = tuple(extra_flags) + tuple(os.environ.get("CNERF_EXTRA_FLAGS", "").split())
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     objs, jobs = [], []
-    for src in SOURCES:
+    # (source, object, extra defines): field_h3.hip is compiled twice -- fp16x3 split kernel and the single-pass fp16 kernel
+    units = [(src, src.replace(".hip", ".o"), ()) for src in SOURCES] + [("field_h3.hip", "field_h1.o", ("-DCNERF_H3_PARTS=1",))]
+    for src, obj, defs in units:
         s = os.path.join(CSRC, src)
-        o = os.path.join(CSRC, src.replace(".hip", ".o"))
+        o = os.path.join(CSRC, obj)
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            jobs.append([hipcc, *FLAGS, *extra_flags, "-c", s, "-o", o])
+            jobs.append([hipcc, *FLAGS, *defs, *extra_flags, "-c", s, "-o", o])
     if jobs:      # the translation units are independent: compile them side by side (a handful of processes)
         from concurrent.futures import ThreadPoolExecutor
 

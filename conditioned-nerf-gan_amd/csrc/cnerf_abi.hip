@@ -53,11 +53,12 @@ int check_cfg(const cnerf_cfg* c, bool need_render) {
         if (l == 0 && k == CNERF_LAYER_RES) return fail(CNERF_EINVAL, "layer 0 cannot be a residual block");
     }
     if (!(c->voxel_length > 0.f)) return fail(CNERF_EINVAL, "voxel_length must be > 0");
-    if (c->precision != CNERF_PREC_FP32 && c->precision != CNERF_PREC_FP16X3) return fail(CNERF_EINVAL, "precision=%d unknown", c->precision);
-    if (c->precision == CNERF_PREC_FP16X3)
+    if (c->precision != CNERF_PREC_FP32 && c->precision != CNERF_PREC_FP16X3 && c->precision != CNERF_PREC_FP16)
+        return fail(CNERF_EINVAL, "precision=%d unknown", c->precision);
+    if (c->precision != CNERF_PREC_FP32)
         for (int l = 0; l < c->L; ++l)
             if (c->layer_kind[l] == CNERF_LAYER_PFILM)
-                return fail(CNERF_EINVAL, "precision fp16x3 does not cover the per-point FiLM family");
+                return fail(CNERF_EINVAL, "precisions fp16x3 / fp16 do not cover the per-point FiLM family");
     if (need_render) {
         if (c->R < 1 || c->R > 4096) return fail(CNERF_EINVAL, "R=%d out of range [1,4096]", c->R);
         if (c->S < 2 || c->S > 128) return fail(CNERF_EINVAL, "S=%d out of range [2,128]", c->S);
@@ -99,7 +100,8 @@ PackedLayout packed_layout(const cnerf_cfg* c) {
     }
     p.n_in = c->C / 32 + ((c->flags & CNERF_F_INPUT_XYZ) ? 1 : 0);
     p.k0 = c->C + ((c->flags & CNERF_F_INPUT_XYZ) ? 3 : 0);
-    if (c->precision == CNERF_PREC_FP16X3) {
+    if (c->precision == CNERF_PREC_FP16X3 || c->precision == CNERF_PREC_FP16) {
+        const size_t parts = c->precision == CNERF_PREC_FP16 ? 1 : 2;
         // fp16 fragments: (t, k-chunk of 16, part) x 64 lanes x 8 fp16 = 256 floats' worth of bytes per (t, c, part);
         // behind the biases: 1/S of every matrix (L + 1), then the max|W| scratch slots (L + 1), padded to 4 floats
         const size_t frag = 64 * 8 / 2;   // in floats
@@ -107,12 +109,12 @@ PackedLayout packed_layout(const cnerf_cfg* c) {
         for (int l = 0; l < c->L; ++l) {
             const size_t kc = (l == 0) ? 2 * (size_t)p.n_in : 2 * NT;
             const size_t n = c->layer_kind[l] == CNERF_LAYER_RES ? 2 : 1;      // residual block: fc1 and fc2
-            p.weight_floats += n * NT * kc * 2 * frag;
+            p.weight_floats += n * NT * kc * parts * frag;
             p.bias_floats += n * c->H;
             mats += n;
             if (c->layer_kind[l] == CNERF_LAYER_FILM) p.n_film++;
         }
-        p.weight_floats += 1 * 2 * NT * 2 * frag;   // head, one 32-row tile
+        p.weight_floats += 1 * 2 * NT * parts * frag;   // head, one 32-row tile
         p.bias_floats += 4 + (2 * (mats + 1) + 3) / 4 * 4;
         return p;
     }
@@ -190,7 +192,9 @@ int fill_field_args(FieldArgs& a, const cnerf_cfg* c, const cnerf_volumes* vols,
 }
 
 hipError_t launch_forward(const FieldArgs& a, const cnerf_cfg* c, hipStream_t stream) {
-    return c->precision == CNERF_PREC_FP16X3 ? launch_field_h3(a, c->H, stream) : launch_field(a, c->H, stream);
+    if (c->precision == CNERF_PREC_FP16X3) return launch_field_h3(a, c->H, stream);
+    if (c->precision == CNERF_PREC_FP16) return launch_field_h1(a, c->H, stream);
+    return launch_field(a, c->H, stream);
 }
 
 void set_points(FieldArgs& a, int B, long long n_per_image) {
@@ -283,8 +287,10 @@ int cnerf_pack_field(const cnerf_cfg* cfg, const cnerf_field_params* p, float* p
         if (hipError_t e = launch_fill(bdst + H, 0.0f, H, stream)) return hip_fail(e, "fill");
         return CNERF_OK;
     }
-    if (cfg->precision == CNERF_PREC_FP16X3) {
+    if (cfg->precision == CNERF_PREC_FP16X3 || cfg->precision == CNERF_PREC_FP16) {
         const size_t frag = 64 * 8 / 2;
+        const size_t parts = cfg->precision == CNERF_PREC_FP16 ? 1 : 2;
+        auto pack16 = cfg->precision == CNERF_PREC_FP16 ? launch_pack_h1 : launch_pack_h3;
         int mats = 0;
         for (int l = 0; l < cfg->L; ++l) mats += cfg->layer_kind[l] == CNERF_LAYER_RES ? 2 : 1;
         float* inv_scale = packed + pl.weight_floats + (size_t)mats * H + 4;     // 1/S per matrix and the head's, then the max|W| scratch
@@ -298,15 +304,15 @@ int cnerf_pack_field(const cnerf_cfg* cfg, const cnerf_field_params* p, float* p
             for (int half = 0; half < (res ? 2 : 1); ++half) {
                 const float* w = half ? p->w2[l] : p->w[l];
                 const float* b = half ? p->b2[l] : p->b[l];
-                if (hipError_t e = launch_pack_h3(w, H, K, NT, l == 0, wdst, inv_scale + m, wmax + m, stream)) return hip_fail(e, "pack_h3");
-                wdst += (size_t)NT * ((K + 31) / 32 * 2) * 2 * frag;
+                if (hipError_t e = pack16(w, H, K, NT, l == 0, wdst, inv_scale + m, wmax + m, stream)) return hip_fail(e, "pack_h3");
+                wdst += (size_t)NT * ((K + 31) / 32 * 2) * parts * frag;
                 if (hipError_t e = hipMemcpyAsync(bdst, b, H * sizeof(float), hipMemcpyDeviceToDevice, stream)) return hip_fail(e, "bias copy");
                 bdst += H;
                 ++m;
             }
         }
         if (!p->w_final || !p->b_final) return fail(CNERF_EINVAL, "pack_field: head is NULL");
-        if (hipError_t e = launch_pack_h3(p->w_final, 4, H, 1, false, wdst, inv_scale + m, wmax + m, stream)) return hip_fail(e, "pack_h3");
+        if (hipError_t e = pack16(p->w_final, 4, H, 1, false, wdst, inv_scale + m, wmax + m, stream)) return hip_fail(e, "pack_h3");
         if (hipError_t e = hipMemcpyAsync(bdst, p->b_final, 4 * sizeof(float), hipMemcpyDeviceToDevice, stream)) return hip_fail(e, "bias copy");
         bdst = packed + pl.weight_floats + pl.bias_floats;
         if (hipError_t e = launch_fill(bdst, 1.0f, H, stream)) return hip_fail(e, "fill");
@@ -453,7 +459,8 @@ int cnerf_render_forward(const cnerf_cfg* cfg, const cnerf_volumes* vols, const 
     };
     const bool keep = aux && aux->act16[0].h;
     if (keep) {
-        if (cfg->precision != CNERF_PREC_FP16X3) return fail(CNERF_EINVAL, "render_forward: act16 needs precision CNERF_PREC_FP16X3");
+        if (cfg->precision != CNERF_PREC_FP16X3 && cfg->precision != CNERF_PREC_FP16)
+            return fail(CNERF_EINVAL, "render_forward: act16 needs precision CNERF_PREC_FP16X3 or CNERF_PREC_FP16");
         if (!aux->act16[0].feat || !aux->act16[0].c || (hier && (!aux->act16[1].feat || !aux->act16[1].h || !aux->act16[1].c)))
             return fail(CNERF_EINVAL, "render_forward: act16 is incomplete");
     }

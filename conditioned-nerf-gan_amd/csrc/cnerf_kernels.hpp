@@ -63,6 +63,9 @@ hipError_t launch_fill(float* dst, float value, int n, hipStream_t stream);
 hipError_t launch_pack_matrix(const float* w, int n_out, int K_real, int OT, float* dst, hipStream_t stream);
 hipError_t launch_field(const FieldArgs& a, int H, hipStream_t stream);
 hipError_t launch_field_h3(const FieldArgs& a, int H, hipStream_t stream);
+hipError_t launch_field_h1(const FieldArgs& a, int H, hipStream_t stream);      // field_h3.hip compiled with CNERF_H3_PARTS=1
+hipError_t launch_pack_h1(const float* w, int n_out, int K_real, int OT, bool k_outer, void* dst, float* inv_scale_slot, float* wmax_slot,
+                          hipStream_t stream);
 hipError_t launch_pack_h3(const float* w, int n_out, int K_real, int OT, bool k_outer, void* dst, float* inv_scale_slot, float* wmax_slot,
                           hipStream_t stream);
 hipError_t launch_field_backward(const FieldArgs& a, int H, hipStream_t stream);

@@ -30,11 +30,32 @@
 #include "field_common.hpp"
 #include "bwd16.hpp"
 
+// This translation unit is compiled TWICE (build.py): CNERF_H3_PARTS = 2 (default) is the fp16x3 kernel described above,
+// CNERF_H3_PARTS = 1 (-> field_h1.o, precision "fp16") keeps only the leading fp16 part of every operand: one MFMA per 16 k-values
+// instead of three, no remainder arithmetic -- plain fp16 products with fp32 accumulation, the numerics class of the reference's
+// own GPU path (torch.cuda.amp.autocast, utils.py:327,643) and of BASELINE config 5 ("bf16 SIREN on MFMA"; fp16 rather than bf16:
+// same MFMA rate, 8x smaller operand rounding, and the operands here are bounded -- sines -- or scaled by a power of two).  Same
+// kernel structure, same packed-stream order with one plane per fragment pair, its own symbol names (inner namespace).
+#ifndef CNERF_H3_PARTS
+#define CNERF_H3_PARTS 2
+#endif
+#if CNERF_H3_PARTS == 1
+#define H3_NS h1
+#define H3_LAUNCH_FIELD launch_field_h1
+#define H3_LAUNCH_PACK launch_pack_h1
+#else
+#define H3_NS h3
+#define H3_LAUNCH_FIELD launch_field_h3
+#define H3_LAUNCH_PACK launch_pack_h3
+#endif
+
 namespace cnerf {
+namespace H3_NS {
 
+constexpr int PARTS = CNERF_H3_PARTS;
 
-struct Split2 {          // eight fp32 values as two fp16 fragments; dword d of a fragment = elements 2d (low half), 2d+1
-    u32x4 p[2];
+struct Split2 {          // eight fp32 values as PARTS fp16 fragments; dword d of a fragment = elements 2d (low half), 2d+1
+    u32x4 p[PARTS];
     __device__ __forceinline__ f16x8 frag(int k) const { return __builtin_bit_cast(f16x8, p[k]); }
 };
 
@@ -46,11 +67,15 @@ __device__ __forceinline__ uint32_t pk_rtz(float a, float b) { return __builtin_
 // by < 6e-8 absolute, nothing at the scale of activations and scaled weights), lo = remainder, again truncated.
 template <int D>
 __device__ __forceinline__ void split_pair(float v0, float v1, Split2& s) {
-    s.p[0][D] = pk_rtz(v0, v1);
-    // (a v_fma_mix_f32 against the packed half itself is one op instead of and + sub but measured no faster)
-    const float r0 = v0 - __uint_as_float(__float_as_uint(v0) & 0xffffe000u);
-    const float r1 = v1 - __uint_as_float(__float_as_uint(v1) & 0xffffe000u);
-    s.p[1][D] = pk_rtz(r0, r1);
+    if constexpr (PARTS == 1) {
+        s.p[0][D] = pk_f16(v0, v1);          // the only part: round to nearest (truncation would bias every product low)
+    } else {
+        s.p[0][D] = pk_rtz(v0, v1);
+        // (a v_fma_mix_f32 against the packed half itself is one op instead of and + sub but measured no faster)
+        const float r0 = v0 - __uint_as_float(__float_as_uint(v0) & 0xffffe000u);
+        const float r1 = v1 - __uint_as_float(__float_as_uint(v1) & 0xffffe000u);
+        s.p[PARTS - 1][D] = pk_rtz(r0, r1);
+    }
 }
 
 // layer-0 inputs (looked-up features, positions) are not bounded like sine outputs: clamp to fp16's range first
@@ -104,14 +129,14 @@ __global__ void pack_h3_kernel(const float* __restrict__ w, int n_out, int K_rea
         // fragment pair index: (t, c) row-major, or -- layer 0 -- input tile outermost so that the two chunks of one input tile
         // for all output tiles form one contiguous weight unit
         const size_t pair = k_outer ? ((size_t)(c >> 1) * OT + t) * 2 + (c & 1) : (size_t)tc;
-        const size_t base = (pair * 2) * 64 * 8 + (size_t)lane * 8 + j;
+        const size_t base = (pair * PARTS) * 64 * 8 + (size_t)lane * 8 + j;
         dst[base] = a0;
-        dst[base + 64 * 8] = a1;
+        if (PARTS == 2) dst[base + 64 * 8] = a1;
     }
 }
 
-hipError_t launch_pack_h3(const float* w, int n_out, int K_real, int OT, bool k_outer, void* dst, float* inv_scale_slot, float* wmax_slot,
-                          hipStream_t stream) {
+static hipError_t pack_impl(const float* w, int n_out, int K_real, int OT, bool k_outer, void* dst, float* inv_scale_slot, float* wmax_slot,
+                            hipStream_t stream) {
     if (hipError_t e = hipMemsetAsync(wmax_slot, 0, sizeof(float), stream)) return e;
     const long long n = (long long)n_out * K_real;
     long long rb = (n + 255) / 256;
@@ -174,7 +199,7 @@ __device__ __forceinline__ void film_split_pair(const f32x16& acc, float inv_s, 
                                                 ActStore& st) {
     float a0 = __builtin_fmaf(acc[r], inv_s, f.bs[0]), a1 = __builtin_fmaf(acc[r + 1], inv_s, f.bs[1]);
     if (RESID) {
-        const uint32_t xh = out2[r >> 3].p[0][(r & 7) >> 1], xl = out2[r >> 3].p[1][(r & 7) >> 1];
+        const uint32_t xh = out2[r >> 3].p[0][(r & 7) >> 1], xl = PARTS == 2 ? out2[r >> 3].p[PARTS - 1][(r & 7) >> 1] : 0u;
         a0 = (half_lo(xh) + half_lo(xl)) + a0;
         a1 = (half_hi(xh) + half_hi(xl)) + a1;
     } else {
@@ -241,7 +266,7 @@ __device__ __forceinline__ void film_split(const f32x16& acc, float inv_s, const
 template <int NT>
 struct H3Lds {
     static constexpr int KC = 2 * NT;
-    static constexpr int PIECES = KC * 2;              // 1-KiB pieces (64 fragments) per weight unit
+    static constexpr int PIECES = KC * PARTS;          // 1-KiB pieces (64 fragments) per weight unit
     static constexpr int FRAGS = PIECES * 64;          // f16x8 fragments per weight unit
     static constexpr int PER_WAVE = PIECES / 4;        // pieces each wave copies
 };
@@ -271,12 +296,16 @@ __device__ __forceinline__ void dma_unit_flat(const f16x8* __restrict__ src, f16
         if (4 * q + 3 < PW) dma_piece<3072>(sq, dq);
     }
 }
+#if CNERF_H3_PARTS == 1
+#define H3_MFMA3(acc, a, xs) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], (xs).frag(0), acc, 0, 0, 0)
+#else
 #define H3_MFMA3(acc, a, xs)                                                                  \
     do {                                                                                       \
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], (xs).frag(0), acc, 0, 0, 0);        \
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], (xs).frag(1), acc, 0, 0, 0);        \
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], (xs).frag(0), acc, 0, 0, 0);        \
     } while (0)
+#endif
 
 // acc (one 32-row output tile) += W_unit * x, A fragments from the LDS copy of the unit; the caller's functor runs once
 // per k-chunk (the pipelined epilogue of the previous output tile).  VALU_PER_MFMA sizes the interleave groups.
@@ -284,27 +313,27 @@ template <int NT, int VALU_PER_MFMA, typename PerChunk>
 __device__ __forceinline__ f32x16 h3_tile_from_lds(const f16x8* lds_tile, const Split2* x, f32x16 acc, int lane, PerChunk per_chunk) {
     constexpr int KC = 2 * NT;
     constexpr int AHEAD = 2;
-    f16x8 ring[AHEAD][2];
+    f16x8 ring[AHEAD][PARTS];
 #pragma unroll
     for (int i = 0; i < AHEAD; ++i)
 #pragma unroll
-        for (int k = 0; k < 2; ++k) ring[i][k] = lds_tile[(i * 2 + k) * 64 + lane];
+        for (int k = 0; k < PARTS; ++k) ring[i][k] = lds_tile[(i * PARTS + k) * 64 + lane];
 #pragma unroll
     for (int c = 0; c < KC; ++c) {
-        f16x8 a[2];
+        f16x8 a[PARTS];
 #pragma unroll
-        for (int k = 0; k < 2; ++k) a[k] = ring[c % AHEAD][k];
+        for (int k = 0; k < PARTS; ++k) a[k] = ring[c % AHEAD][k];
         if (c + AHEAD < KC) {
 #pragma unroll
-            for (int k = 0; k < 2; ++k) ring[c % AHEAD][k] = lds_tile[((c + AHEAD) * 2 + k) * 64 + lane];
+            for (int k = 0; k < PARTS; ++k) ring[c % AHEAD][k] = lds_tile[((c + AHEAD) * PARTS + k) * 64 + lane];
         }
         H3_MFMA3(acc, a, x[c]);          // small terms first, the leading product last
         per_chunk(c);
         if (VALU_PER_MFMA > 0) {
 #pragma unroll
-            for (int m = 0; m < 3; ++m) {
+            for (int m = 0; m < (PARTS == 1 ? 1 : 3); ++m) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, VALU_PER_MFMA, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, PARTS == 1 ? 3 * VALU_PER_MFMA : VALU_PER_MFMA, 0);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -317,19 +346,19 @@ template <int NT>
 __device__ __forceinline__ void h3_layer0_from_lds(const f16x8* lds_unit, const Split2* f2, f32x16* acc0, int lane) {
     constexpr int Q = 2 * NT;
     constexpr int AHEAD = 2;
-    f16x8 ring[AHEAD][2];
+    f16x8 ring[AHEAD][PARTS];
 #pragma unroll
     for (int i = 0; i < AHEAD; ++i)
 #pragma unroll
-        for (int k = 0; k < 2; ++k) ring[i][k] = lds_unit[(i * 2 + k) * 64 + lane];
+        for (int k = 0; k < PARTS; ++k) ring[i][k] = lds_unit[(i * PARTS + k) * 64 + lane];
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
-        f16x8 a[2];
+        f16x8 a[PARTS];
 #pragma unroll
-        for (int k = 0; k < 2; ++k) a[k] = ring[q % AHEAD][k];
+        for (int k = 0; k < PARTS; ++k) a[k] = ring[q % AHEAD][k];
         if (q + AHEAD < Q) {
 #pragma unroll
-            for (int k = 0; k < 2; ++k) ring[q % AHEAD][k] = lds_unit[((q + AHEAD) * 2 + k) * 64 + lane];
+            for (int k = 0; k < PARTS; ++k) ring[q % AHEAD][k] = lds_unit[((q + AHEAD) * PARTS + k) * 64 + lane];
         }
         f32x16 acc = acc0[q >> 1];
         H3_MFMA3(acc, a, f2[q & 1]);
@@ -670,7 +699,7 @@ static hipError_t launch_h3_nt(const FieldArgs& a, hipStream_t stream) {
     return launch_h3_inst<NT, STORE, false, false>(a, stream);
 }
 
-hipError_t launch_field_h3(const FieldArgs& a, int H, hipStream_t stream) {
+static hipError_t field_impl(const FieldArgs& a, int H, hipStream_t stream) {
     if (a.n_in < 1 || a.in_level[0] < 0) return hipErrorInvalidValue;      // the cross-tile lookup prefetch assumes a volume tile first
     // a.act_h set: activation-storing forward of the backward pass, fp32 rows or (a.act_tb16) fp16 tile blocks
     const int store = a.act_h == nullptr ? STORE_NONE : (a.act_tb16 ? STORE_TB16 : STORE_F32);
@@ -681,5 +710,14 @@ hipError_t launch_field_h3(const FieldArgs& a, int H, hipStream_t stream) {
         default: return hipErrorInvalidValue;
     }
 }
+
+}  // namespace H3_NS
+
+hipError_t H3_LAUNCH_PACK(const float* w, int n_out, int K_real, int OT, bool k_outer, void* dst, float* inv_scale_slot, float* wmax_slot,
+                          hipStream_t stream) {
+    return H3_NS::pack_impl(w, n_out, K_real, OT, k_outer, dst, inv_scale_slot, wmax_slot, stream);
+}
+
+hipError_t H3_LAUNCH_FIELD(const FieldArgs& a, int H, hipStream_t stream) { return H3_NS::field_impl(a, H, stream); }
 
 }  // namespace cnerf

@@ -48,12 +48,13 @@ def volumes_struct(levels):
 
 
 def precision_of(net):
-    """Forward arithmetic of `net`: its `.precision` attribute ("fp32" | "fp16x3"), fp16x3 only where the kernel has it
-    (FiLM / plain-sine / residual layers; the per-point FiLM family runs in fp32)."""
+    """Forward arithmetic of `net`: its `.precision` attribute -- "fp32" (exact fp32 MFMA), "fp16x3" (fp32-accurate three-way
+    fp16 split, same parity gate) or "fp16" (plain fp16 products with fp32 sums: the reference's autocast class, ~1e-3) -- the
+    fp16 kernels only where they exist (FiLM / plain-sine / residual layers; the per-point FiLM family runs in fp32)."""
     p = getattr(net, "precision", "fp32")
     if p not in L.PREC_CODE:
         raise L.CnerfError(f"unknown precision {p!r}")
-    if p == "fp16x3" and any(k not in ("film", "sine", "res") for k in net.spec.layers):
+    if p != "fp32" and any(k not in ("film", "sine", "res") for k in net.spec.layers):
         return "fp32"
     return p
 
@@ -673,7 +674,7 @@ class RenderFunction(torch.autograd.Function):
         need_grad = any(ctx.needs_input_grad)   # (grad mode is always off inside Function.forward)
         keys = SAVED_KEYS + (("coarse_points", "fine_points") if net.spec.layers[0] == "pfilm" else ())   # see _pfilm_backward
         act16 = None
-        if need_grad and backward_precision_of(net) == "fp16" and precision_of(net) == "fp16x3":
+        if need_grad and backward_precision_of(net) == "fp16" and precision_of(net) in ("fp16x3", "fp16"):
             act16 = resident_act16(net, levels, cam2world.shape[0], o["R"], o["S"], o["hier"], cam2world.device)
         pixels, depth, aux = render_forward(net, levels, fr, ph, cam2world, o["R"], o["fov"], o["ray_start"], o["ray_end"],
                                             o["S"], o["hier"], o["clamp_mode"], o["noise_std"], o["white_back"],

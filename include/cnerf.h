@@ -42,6 +42,10 @@ extern "C" {
 
 /* cnerf_cfg.precision */
 #define CNERF_PREC_FP32 0   /* v_mfma_f32_32x32x2_f32: exact fp32 fmaf chains */
+#define CNERF_PREC_FP16 1   /* plain fp16 products, fp32 accumulation (one v_mfma_f32_32x32x16_f16 per 16 k-values; weights pre-scaled per
+                             * matrix by a power of two, activations rounded to nearest): the numerics class of the reference's GPU path
+                             * (torch.cuda.amp.autocast, utils.py:327,643) and of BASELINE config 5; NOT inside the 1e-4 gate (measured
+                             * ~1e-3 on rgb / sigma: tests/test_gpu_parity.py::test_single_pass_fp16) -- use fp16x3 for that */
 #define CNERF_PREC_FP16X3 2 /* every fp32 operand split into two fp16 parts (22 significant bits), three fp16 MFMAs per product
                              * with fp32 accumulation, weights pre-scaled per matrix by a power of two: fp32-level accuracy
                              * (same parity gate) at 3/16 of the fp32 matrix time; forward and the activation-storing re-run of the

@@ -70,6 +70,16 @@ def main():
         if rank == 0:
             print(f"resumed from {args.resume} at step {ck['step']}", flush=True)
     gen = torch.Generator().manual_seed(1000 + rank)
+    import threading
+    first_done = threading.Event()
+
+    def heartbeat():                       # kernel selection / compilation by MIOpen takes minutes with the search on: keep talking
+        t0 = time.perf_counter()
+        while not first_done.wait(60.0):
+            print(f"... still selecting convolution kernels / running the first step ({time.perf_counter() - t0:.0f} s, MIOpen find mode)", flush=True)
+
+    if rank == 0:
+        threading.Thread(target=heartbeat, daemon=True).start()
     if md["miopen_find"]:
         # MIOpen's kernel search runs once per node: rank 0 first, the others after it (they find its results in the shared user
         # database instead of searching for ~7 minutes each, all at once)
@@ -85,16 +95,6 @@ def main():
             if rank != 0:
                 trainer.warm_convolutions(warm)
             dist.barrier()
-    import threading
-    first_done = threading.Event()
-
-    def heartbeat():                       # the first step selects (and compiles) MIOpen kernels: minutes with the search on
-        t0 = time.perf_counter()
-        while not first_done.wait(60.0):
-            print(f"... first step still running ({time.perf_counter() - t0:.0f} s: MIOpen kernel selection)", flush=True)
-
-    if rank == 0:
-        threading.Thread(target=heartbeat, daemon=True).start()
     for step in range(args.steps):
         sample = synthetic_sample(args.batch, args.img_size, args.voxel_res, dev, gen)
         torch.cuda.synchronize()
