@@ -51,9 +51,26 @@ def fancy_integration(rgb_sigma, z_vals, device=None, noise_std=0.5, last_back=F
     rgb, dist, w = ops.composite(rgb_sigma.reshape(B * P, S, 4), z_vals.reshape(B * P, S),
                                  noise.reshape(B * P, S) if noise_std != 0 else None, noise_std, clamp_mode, white_back,
                                  last_back)
+    rgb = rgb.reshape(B, P, 3)
     if fill_mode is not None:
-        raise NotImplementedError("fill_mode debug paths are not part of the HIP render path")
-    return rgb.reshape(B, P, 3), dist.reshape(B, P, 1), w.reshape(B, P, S, 1)
+        # debug paints of the reference (volumetric_rendering.py:62-67), on the composited result: `weights_sum` there is taken
+        # BEFORE the last_back correction, i.e. the plain sum of alpha * transmittance
+        wsum = w.reshape(B, P, S).sum(-1, keepdim=True)
+        if last_back:
+            wsum = wsum - (w.reshape(B, P, S)[..., -1:] - _last_weight_before_back(rgb_sigma, z_vals, noise, noise_std, clamp_mode))
+        if fill_mode == "debug":
+            rgb = torch.where(wsum < 0.9, torch.tensor([1.0, 0.0, 0.0], device=rgb.device).expand_as(rgb), rgb)
+        elif fill_mode == "weight":
+            rgb = wsum.expand_as(rgb).clone()
+    return rgb, dist.reshape(B, P, 1), w.reshape(B, P, S, 1)
+
+
+def _last_weight_before_back(rgb_sigma, z_vals, noise, noise_std, clamp_mode):
+    """Weight of the last sample without the last_back correction (one more composite call with the flag off)."""
+    B, P, S = rgb_sigma.shape[:3]
+    _, _, w = ops.composite(rgb_sigma.reshape(B * P, S, 4), z_vals.reshape(B * P, S), noise.reshape(B * P, S) if noise_std != 0 else None,
+                            noise_std, clamp_mode, False, False)
+    return w.reshape(B, P, S)[..., -1:]
 
 
 def importance_sample(z_vals, weights, u):

@@ -1034,3 +1034,24 @@ def test_backward_ragged_shapes_vs_oracle_autograd(dev, shape, backward_precisio
             assert e < max(2e-3, 2.5 * floor), (k, e, floor)
         else:
             assert l2 < max(2e-3, 2.5 * rel_l2(w, exact[k])) and e < max(5e-2, 2.5 * floor), (k, e, l2, floor)
+
+
+def test_fancy_integration_fill_modes(dev):
+    """The debug paints of fancy_integration (volumetric_rendering.py:62-67) against the oracle's composite + the reference's
+    two formulas: "debug" paints rays whose weights sum below 0.9 red, "weight" returns the weight sum as colour."""
+    from cnerf_amd.generators.volumetric_rendering import fancy_integration
+    from oracle import render_oracle as O
+    torch.manual_seed(2)
+    rs = torch.randn(2, 50, 9, 4)
+    rs[..., 3] *= 3
+    z = torch.sort(torch.rand(2, 50, 9) * 1.5 + 0.25, -1)[0]
+    for last_back in (False, True):
+        rgb_ref, _, w = O.composite(rs, z, None, 0.0, "relu", white_back=True, last_back=False)
+        wsum = w.sum(-1, keepdim=True)
+        rgb0, _, _ = O.composite(rs, z, None, 0.0, "relu", white_back=True, last_back=last_back)
+        for mode in ("debug", "weight"):
+            got, _, _ = fancy_integration(rs.to(dev), z.unsqueeze(-1).to(dev), dev, noise_std=0.0, last_back=last_back, white_back=True,
+                                          clamp_mode="relu", fill_mode=mode)
+            want = torch.where(wsum < 0.9, torch.tensor([1.0, 0.0, 0.0]).expand_as(rgb0), rgb0) if mode == "debug" else wsum.expand_as(rgb0)
+            near = (wsum - 0.9).abs() < 1e-5            # rays sitting on the threshold may fall either way
+            assert ((got.cpu() - want).abs().max(-1)[0][~near.squeeze(-1)] < 1e-5).all(), (mode, last_back)
