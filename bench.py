@@ -577,6 +577,23 @@ def main():
         if world == 1 and args.precision == "fp32" and not args.no_fast_path:
             res["fp16x3_split_path"] = fast_path(args, gen, fvol, glob, cam, meta, evs)
             res["fp16_single_pass_path"] = fast_path(args, gen, fvol, glob, cam, meta, evs, precision="fp16")
+        if world == 1 and args.precision == "fp32" and not args.no_fast_path:
+            # the same fp32 step with the four draws generated inside the kernels (no torch RNG kernels, no random tensors)
+            gen.rng_mode = "philox"
+            try:
+                with torch.no_grad():
+                    for _ in range(2):
+                        step(None)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(5):
+                        step(None)
+                    torch.cuda.synchronize()
+                    dtp = (time.perf_counter() - t0) / 5
+            finally:
+                gen.rng_mode = "torch"
+            res["philox_rng_path"] = {"value": B * R * R / dtp, "unit": "rays/s", "ms_per_step": dtp * 1e3, "dtype": "f32",
+                                      "note": "in-kernel Philox4x32-10 draws (cnerf_cfg.philox) instead of torch.rand / randn tensors"}
         if world == 1 and not args.no_train_step:
             res["train_step"] = train_step_timing(args, gen, fvol, glob, cam, evs)
         print(json.dumps(res), flush=True)

@@ -22,7 +22,7 @@ class Cfg(C.Structure):
                 ("ray_start", C.c_float), ("ray_end", C.c_float), ("voxel_length", C.c_float),
                 ("noise_std", C.c_float), ("flags", C.c_uint32), ("fov_deg", C.c_double),
                 ("n_levels", C.c_int32), ("level_V", C.c_int32 * MAX_LEVELS), ("level_C", C.c_int32 * MAX_LEVELS),
-                ("precision", C.c_int32)]
+                ("precision", C.c_int32), ("philox", C.c_uint32), ("philox_offset", C.c_uint32), ("philox_seed", C.c_uint64)]
 
 
 class Volumes(C.Structure):
@@ -56,6 +56,7 @@ class Aux(C.Structure):
 PROTOTYPES = {
     "cnerf_abi_version": (C.c_int, []),
     "cnerf_last_error": (C.c_char_p, []),
+    "cnerf_philox_fill": (C.c_int, [C.c_uint64, C.c_uint32, C.c_uint32, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "cnerf_workspace_bytes": (C.c_int, [C.POINTER(Cfg), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "cnerf_fvol_channel_last": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cnerf_fvol_channel_first": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -134,6 +134,10 @@ PackedLayout packed_layout(const cnerf_cfg* c) {
     return p;
 }
 
+PhiloxKey philox_of(const cnerf_cfg* c) {
+    return PhiloxKey{c->philox ? 1u : 0u, c->philox_offset, (uint32_t)(c->philox_seed & 0xffffffffull), (uint32_t)(c->philox_seed >> 32)};
+}
+
 RayGeom make_geom(const cnerf_cfg* c) {
     RayGeom g;
     g.R = c->R;
@@ -188,6 +192,8 @@ int fill_field_args(FieldArgs& a, const cnerf_cfg* c, const cnerf_volumes* vols,
     for (int l = 0; l < c->L; ++l) a.n_mats += c->layer_kind[l] == CNERF_LAYER_RES ? 2 : 1;
     a.flags = c->flags;
     for (int l = 0; l < c->L; ++l) a.layer_kind[l] = c->layer_kind[l];
+    a.philox = philox_of(c);
+    a.image0 = image0;
     return CNERF_OK;
 }
 
@@ -210,6 +216,14 @@ extern "C" {
 int cnerf_abi_version(void) { return CNERF_ABI_VERSION; }
 
 const char* cnerf_last_error(void) { return g_err; }
+
+int cnerf_philox_fill(uint64_t seed, uint32_t offset, uint32_t stream_id, int64_t n, int32_t normal, float* out, void* stream) {
+    g_err[0] = 0;
+    if (!out || n < 1 || stream_id > 3) return fail(CNERF_EINVAL, "philox_fill: bad argument (stream_id 0..3)");
+    const PhiloxKey k{1u, offset, (uint32_t)(seed & 0xffffffffull), (uint32_t)(seed >> 32)};
+    if (hipError_t e = launch_philox_fill(k, stream_id, (long long)n, normal, out, (hipStream_t)stream)) return hip_fail(e, "philox_fill");
+    return CNERF_OK;
+}
 
 int cnerf_workspace_bytes(const cnerf_cfg* cfg, size_t* packed, size_t* fvol_cl, size_t* fwd_ws) {
     g_err[0] = 0;
@@ -407,7 +421,7 @@ int cnerf_resample(int64_t rays, int32_t S, const float* z, const float* weights
                    int32_t* inds, float* cdf, void* stream) {
     g_err[0] = 0;
     if (rays < 1 || S < 2 || S > 128 || !z || !weights || !u || !fine_z) return fail(CNERF_EINVAL, "resample: bad argument (2 <= S <= 128)");
-    ResampleArgs a{z, weights, nullptr, nullptr, u, fine_z, inds, cdf, nullptr, (long long)rays, S, 0.0f, 0u};
+    ResampleArgs a{z, weights, nullptr, nullptr, u, fine_z, inds, cdf, nullptr, (long long)rays, S, 0.0f, 0u, PhiloxKey{0u, 0u, 0u, 0u}};
     if (hipError_t e = launch_resample(a, (hipStream_t)stream)) return hip_fail(e, "resample");
     return CNERF_OK;
 }
@@ -423,7 +437,7 @@ int cnerf_render_forward(const cnerf_cfg* cfg, const cnerf_volumes* vols, const 
     const bool hier = cfg->flags & CNERF_F_HIERARCHICAL;
     static const cnerf_rng no_rng = {nullptr, nullptr, nullptr, nullptr, nullptr};
     if (!rng) rng = &no_rng;
-    if (hier && !rng->u_fine) return fail(CNERF_EINVAL, "render_forward: hierarchical sampling needs rng.u_fine");
+    if (hier && !rng->u_fine && !cfg->philox) return fail(CNERF_EINVAL, "render_forward: hierarchical sampling needs rng.u_fine (or cfg.philox)");
     hipStream_t stream = (hipStream_t)stream_;
 
     const long long P = (long long)cfg->R * cfg->R, S = cfg->S;
@@ -480,7 +494,7 @@ int cnerf_render_forward(const cnerf_cfg* cfg, const cnerf_volumes* vols, const 
         // 2. coarse weights -> inverse-CDF depths
         ResampleArgs ra{c_z, nullptr, c_rs, rng->eps_coarse, rng->u_fine, f_z, aux ? aux->inds : nullptr,
                         aux ? aux->cdf : nullptr, aux ? aux->coarse_weights : nullptr, (long long)cfg->B * P, (int)S,
-                        cfg->noise_std, cfg->flags};
+                        cfg->noise_std, cfg->flags, philox_of(cfg)};
         if (hipError_t e = launch_resample(ra, stream)) return hip_fail(e, "resample");
         // 3. fine pass
         fa.mode = FIELD_MODE_FINE;
@@ -498,7 +512,7 @@ int cnerf_render_forward(const cnerf_cfg* cfg, const cnerf_volumes* vols, const 
     // 4. merge + composite + epilogue
     MergeArgs ma{c_rs, c_z, hier ? f_rs : nullptr, hier ? f_z : nullptr, rng->eps_final, pixels, depth,
                  aux ? aux->sort_idx : nullptr, aux ? aux->final_weights : nullptr, (long long)cfg->B * P, (int)S,
-                 make_geom(cfg), cfg->noise_std, cfg->flags};
+                 make_geom(cfg), cfg->noise_std, cfg->flags, philox_of(cfg)};
     if (hipError_t e = launch_merge_composite(ma, stream)) return hip_fail(e, "merge_composite");
     return CNERF_OK;
 }
@@ -553,7 +567,7 @@ int cnerf_merge_composite_backward(const cnerf_cfg* cfg, const float* coarse_rgb
     if (hier && (!fine_rgb_sigma || !fine_z || !grad_fine)) return fail(CNERF_EINVAL, "merge_composite_backward: fine tensors missing");
     MergeBwdArgs a{coarse_rgb_sigma, coarse_z, hier ? fine_rgb_sigma : nullptr, hier ? fine_z : nullptr, eps_final,
                    grad_pixels, grad_depth, grad_coarse, hier ? grad_fine : nullptr,
-                   (long long)cfg->B * cfg->R * cfg->R, cfg->S, make_geom(cfg), cfg->noise_std, cfg->flags};
+                   (long long)cfg->B * cfg->R * cfg->R, cfg->S, make_geom(cfg), cfg->noise_std, cfg->flags, philox_of(cfg)};
     if (hipError_t e = launch_merge_composite_backward(a, (hipStream_t)stream)) return hip_fail(e, "merge_composite_backward");
     return CNERF_OK;
 }

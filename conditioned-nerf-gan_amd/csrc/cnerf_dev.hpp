@@ -160,6 +160,49 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// In-kernel random draws: Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11), counter-based:
+// the draw of element `idx` of stream `stream` (0 u_strat, 1 eps_coarse, 2 u_fine, 3 eps_final -- the reference's four draws,
+// volumetric_rendering.py:39,106,319) of call `offset` under `seed` is a pure function of those four numbers, so forward,
+// re-computed forward and backward see the same values without a tensor in between.  counter = (idx lo, idx hi, stream,
+// offset), key = (seed lo, seed hi).  uniform: top 24 bits of word 0 -> [0, 1) in steps of 2^-24 (torch.rand's grid);
+// normal: Box-Muller on words 0, 1.  oracle/philox.py is the NumPy twin (known-answer tested).
+// ---------------------------------------------------------------------------------------------------------------
+struct PhiloxKey {
+    uint32_t on, offset, seed_lo, seed_hi;
+};
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0;
+        c1 = lo1;
+        c2 = n2;
+        c3 = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0;
+    out[1] = c1;
+    out[2] = c2;
+    out[3] = c3;
+}
+__device__ __forceinline__ float philox_uniform(const PhiloxKey& k, uint32_t stream, unsigned long long idx) {
+    uint32_t o[4];
+    philox4x32_10((uint32_t)idx, (uint32_t)(idx >> 32), stream, k.offset, k.seed_lo, k.seed_hi, o);
+    return (float)(o[0] >> 8) * 5.9604644775390625e-08f;           // * 2^-24
+}
+__device__ __forceinline__ float philox_normal(const PhiloxKey& k, uint32_t stream, unsigned long long idx) {
+    uint32_t o[4];
+    philox4x32_10((uint32_t)idx, (uint32_t)(idx >> 32), stream, k.offset, k.seed_lo, k.seed_hi, o);
+    const float u1 = (float)((o[0] >> 8) + 1u) * 5.9604644775390625e-08f;     // (0, 1]
+    const float u2 = (float)(o[1] >> 8) * 5.9604644775390625e-08f;            // [0, 1)
+    return sqrtf(-2.0f * logf(u1)) * cosf(6.2831853071795864f * u2);
+}
+enum { PHILOX_U_STRAT = 0, PHILOX_EPS_COARSE = 1, PHILOX_U_FINE = 2, PHILOX_EPS_FINAL = 3 };
+
+// ---------------------------------------------------------------------------------------------------------------
 // rays and sample points (volumetric_rendering.py:73-199, generators.py:138-142)
 // ---------------------------------------------------------------------------------------------------------------
 struct RayGeom {

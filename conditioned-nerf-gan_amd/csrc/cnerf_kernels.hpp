@@ -57,6 +57,8 @@ struct FieldArgs {
     uint32_t flags;
     int mode;
     int layer_kind[CNERF_MAX_LAYERS];
+    PhiloxKey philox;        // in-kernel draw of u_strat where the tensor is null (cnerf_cfg.philox_*)
+    int image0;              // first image of this launch inside the call (global element indices of the draws)
 };
 
 hipError_t launch_fill(float* dst, float value, int n, hipStream_t stream);
@@ -102,6 +104,7 @@ struct ResampleArgs {
     int S;
     float noise_std;
     uint32_t flags;
+    PhiloxKey philox;      // draws eps (coarse) / u (fine) in the kernel where the tensors are null
 };
 hipError_t launch_resample(const ResampleArgs& a, hipStream_t stream);
 
@@ -120,6 +123,7 @@ struct MergeArgs {
     RayGeom geom;
     float noise_std;
     uint32_t flags;
+    PhiloxKey philox;               // draws eps (final) in the kernel where the tensor is null
 };
 hipError_t launch_merge_composite(const MergeArgs& a, hipStream_t stream);
 
@@ -138,9 +142,11 @@ struct MergeBwdArgs {
     RayGeom geom;
     float noise_std;
     uint32_t flags;
+    PhiloxKey philox;
 };
 hipError_t launch_merge_composite_backward(const MergeBwdArgs& a, hipStream_t stream);
 
+hipError_t launch_philox_fill(const PhiloxKey& k, uint32_t stream_id, long long n, int normal, float* out, hipStream_t stream);
 hipError_t launch_transpose_cl(int B, int C, int V, const float* src, float* dst, bool to_channel_last, hipStream_t stream);
 
 struct GatherArgs {

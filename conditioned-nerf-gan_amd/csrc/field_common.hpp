@@ -161,7 +161,8 @@ __device__ __forceinline__ TileRaw tile_point_fetch(const FieldArgs& a, int b, l
         r.v[1] = p[1];
         r.v[2] = p[2];
     } else if (a.mode == FIELD_MODE_COARSE) {
-        r.v[0] = a.u_strat ? a.u_strat[gp] : 0.5f;
+        // the jitter draw: injected tensor, or Philox on the element's index inside the whole call, or none (0.5 = no jitter)
+        r.v[0] = a.u_strat ? a.u_strat[gp] : (a.philox.on ? philox_uniform(a.philox, PHILOX_U_STRAT, (unsigned long long)(b + a.image0) * a.n_per_image + nn) : 0.5f);
     } else {
         r.v[0] = a.fine_z[gp];
     }

@@ -28,7 +28,20 @@ struct RaySums {
 
 // Composites n samples of one ray.  rs/z/eps are indexed by sample; w_keep[c] receives the weight of sample
 // c*64+lane.  Every lane returns the same sums.
-__device__ __forceinline__ RaySums composite_ray(const f32x4* rs, const float* z, const float* eps, int n,
+// density noise of sample i: injected tensor, or Philox (stream `ph_stream`, element ph_base + i), or none
+struct NoiseSrc {
+    const float* eps;
+    PhiloxKey ph;
+    uint32_t ph_stream;
+    unsigned long long ph_base;
+    __device__ __forceinline__ float at(int i, float noise_std) const {
+        if (eps) return eps[i] * noise_std;
+        if (ph.on && noise_std != 0.0f) return philox_normal(ph, ph_stream, ph_base + (unsigned long long)i) * noise_std;
+        return 0.0f;
+    }
+};
+
+__device__ __forceinline__ RaySums composite_ray(const f32x4* rs, const float* z, const NoiseSrc& eps, int n,
                                                  float noise_std, uint32_t flags, float (&w_keep)[CHUNKS], int lane) {
     double carry = 1.0;   // product of (1 - alpha + 1e-10) over all earlier chunks
     double wsum_d = 0.0;
@@ -46,7 +59,7 @@ __device__ __forceinline__ RaySums composite_ray(const f32x4* rs, const float* z
                 const f32x4 v = rs[i];
                 const float zi = z[i];
                 const float delta = (i == n - 1) ? 1e10f : (z[i + 1] - zi);
-                const float noisy = v[3] + (eps ? eps[i] * noise_std : 0.0f);
+                const float noisy = v[3] + eps.at(i, noise_std);
                 const float dens = (flags & CNERF_F_SOFTPLUS) ? softplus20(noisy) : fmaxf(noisy, 0.0f);
                 alpha = 1.0f - expf(-delta * dens);
                 shifted = 1.0f - alpha + 1e-10f;
@@ -101,7 +114,7 @@ __global__ __launch_bounds__(256) void composite_kernel(CompositeArgs a) {
     if (ray >= a.rays) return;
     const f32x4* rs = reinterpret_cast<const f32x4*>(a.rgb_sigma) + ray * a.n;
     const float* z = a.z + ray * a.n;
-    const float* eps = a.eps ? a.eps + ray * a.n : nullptr;
+    const NoiseSrc eps{a.eps ? a.eps + ray * a.n : nullptr, PhiloxKey{0u, 0u, 0u, 0u}, 0u, 0ull};
     float w[CHUNKS];
     const RaySums s = composite_ray(rs, z, eps, a.n, a.noise_std, a.flags, w, lane);
     if (a.weights) {
@@ -135,7 +148,7 @@ __global__ __launch_bounds__(256) void resample_kernel(ResampleArgs a) {
     float w[CHUNKS];
     if (a.rgb_sigma) {
         const f32x4* rs = reinterpret_cast<const f32x4*>(a.rgb_sigma) + ray * S;
-        const float* eps = a.eps ? a.eps + ray * S : nullptr;
+        const NoiseSrc eps{a.eps ? a.eps + ray * S : nullptr, a.philox, PHILOX_EPS_COARSE, (unsigned long long)ray * S};
         (void)composite_ray(rs, z, eps, S, a.noise_std, a.flags & CNERF_F_SOFTPLUS, w, lane);
     } else {
 #pragma unroll
@@ -182,7 +195,7 @@ __global__ __launch_bounds__(256) void resample_kernel(ResampleArgs a) {
     for (int c = 0; c < CHUNKS; ++c) {
         const int s = c * WAVE + lane;
         if (s < S) {
-            const float u = a.u[ray * S + s];
+            const float u = a.u ? a.u[ray * S + s] : philox_uniform(a.philox, PHILOX_U_FINE, (unsigned long long)ray * S + s);
             int lo = 0, hi = ncdf;   // first index with cdf[idx] >= u
             while (lo < hi) {
                 const int mid = (lo + hi) >> 1;
@@ -261,7 +274,7 @@ __global__ __launch_bounds__(256) void merge_composite_kernel(MergeArgs a) {
         rs_sorted = crs;
         z_sorted = cz;
     }
-    const float* eps = a.eps ? a.eps + ray * n : nullptr;
+    const NoiseSrc eps{a.eps ? a.eps + ray * n : nullptr, a.philox, PHILOX_EPS_FINAL, (unsigned long long)ray * n};
     float w[CHUNKS];
     const RaySums s = composite_ray(rs_sorted, z_sorted, eps, n, a.noise_std, a.flags, w, lane);
     if (!live) return;
@@ -360,7 +373,7 @@ __global__ __launch_bounds__(256) void merge_composite_backward_kernel(MergeBwdA
     const float* gp = a.grad_pixels + b * 3 * P + p;
     const float gr = 2.0f * gp[0], gg = 2.0f * gp[P], gb = 2.0f * gp[2 * P];   // pixels = 2 rgb - 1
     const float gd = a.grad_depth ? dz * a.grad_depth[ray] : 0.0f;              // depth = dir_z * dist
-    const float* eps = a.eps ? a.eps + ray * n : nullptr;
+    const NoiseSrc eps{a.eps ? a.eps + ray * n : nullptr, a.philox, PHILOX_EPS_FINAL, (unsigned long long)ray * n};
 
     // forward recompute (same arithmetic as composite_ray) keeping alpha, trans, exp(-delta dens), act'
     float alpha[CHUNKS], trans[CHUNKS], w[CHUNKS], dsig[CHUNKS], sft[CHUNKS];
@@ -379,7 +392,7 @@ __global__ __launch_bounds__(256) void merge_composite_backward_kernel(MergeBwdA
                 const f32x4 v = s_rss[wv][i];
                 const float zi = s_zs[wv][i];
                 const float delta = (i == n - 1) ? 1e10f : (s_zs[wv][i + 1] - zi);
-                const float noisy = v[3] + (eps ? eps[i] * a.noise_std : 0.0f);
+                const float noisy = v[3] + eps.at(i, a.noise_std);
                 float dens, dact;
                 if (a.flags & CNERF_F_SOFTPLUS) {
                     dens = softplus20(noisy);
@@ -565,6 +578,19 @@ __global__ __launch_bounds__(256) void scatter_kernel(GatherArgs a, const float*
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// the draws as tensors (tests, and hosts that want to look at them): out[i] = uniform / normal of element i of a stream
+__global__ void philox_fill_kernel(PhiloxKey k, uint32_t stream_id, long long n, int normal, float* __restrict__ out) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        out[i] = normal ? philox_normal(k, stream_id, (unsigned long long)i) : philox_uniform(k, stream_id, (unsigned long long)i);
+}
+hipError_t launch_philox_fill(const PhiloxKey& k, uint32_t stream_id, long long n, int normal, float* out, hipStream_t stream) {
+    long long blocks = (n + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(philox_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, k, stream_id, n, normal, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_composite(const CompositeArgs& a, hipStream_t stream) {
     const unsigned blocks = (unsigned)((a.rays + RAYS_PER_BLOCK - 1) / RAYS_PER_BLOCK);
     hipLaunchKernelGGL(composite_kernel, dim3(blocks), dim3(256), 0, stream, a);

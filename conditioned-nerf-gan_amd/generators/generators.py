@@ -40,6 +40,10 @@ class ImplicitGenerator3d(nn.Module):
         self.epoch = 0
         self.step = 0
         self.device = None
+        # where the four random draws of a forward come from: "torch" (torch.rand / randn on the device in the reference's
+        # order and shapes -- the default: the torch generator advances as it does there) or "philox" (in-kernel)
+        self.rng_mode = "torch"
+        self._philox_calls = 0
 
     def set_device(self, device):
         self.device = device
@@ -62,7 +66,13 @@ class ImplicitGenerator3d(nn.Module):
         freq, phase = net.film(glob)
         rng = kwargs.get("_rng")
         if rng is None:
-            rng = draw_rng(B, R * R, S, bool(hierarchical_sample), noise_std, dev)
+            if self.rng_mode == "philox":
+                # draws generated inside the kernels (Philox4x32-10): no RNG kernels, no tensors; seeded from torch's CUDA seed,
+                # one counter value per forward of this module
+                rng = {"philox": (torch.cuda.initial_seed(), self._philox_calls)}
+                self._philox_calls += 1
+            else:
+                rng = draw_rng(B, R * R, S, bool(hierarchical_sample), noise_std, dev)
         aux_out = kwargs.get("_aux")
         pixels, depth, aux = ops.render(net, fvol, freq, phase, cam2worlds, R, fov, ray_start, ray_end, S,
                                         bool(hierarchical_sample), clamp_mode, noise_std, white_back, last_back, rng,

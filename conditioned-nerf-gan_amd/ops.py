@@ -60,7 +60,7 @@ def precision_of(net):
 
 
 def make_cfg(net, B, vols, R=1, S=2, fov=30.0, ray_start=0.0, ray_end=1.0, noise_std=0.0, hierarchical=False,
-             white_back=False, last_back=False, clamp_mode="relu", precision=None):
+             white_back=False, last_back=False, clamp_mode="relu", precision=None, philox=None):
     """cnerf_cfg for a field network `net` (generators.siren.FieldNetwork); vols: channel-last volume(s) or, for calls
     that touch no volume, the side V of a single 32-channel one."""
     cfg = L.Cfg()
@@ -96,6 +96,8 @@ def make_cfg(net, B, vols, R=1, S=2, fov=30.0, ray_start=0.0, ray_end=1.0, noise
     flags |= L.F_INPUT_XYZ if net.spec.input == "feat_xyz" else 0
     cfg.flags = flags
     cfg.precision = L.PREC_CODE[precision if precision is not None else precision_of(net)]
+    if philox is not None:            # (seed, offset): draws without a tensor are generated in the kernels
+        cfg.philox, cfg.philox_seed, cfg.philox_offset = 1, int(philox[0]) & 0xFFFFFFFFFFFFFFFF, int(philox[1]) & 0xFFFFFFFF
     return cfg
 
 
@@ -222,6 +224,14 @@ def resample(z, weights, u):
     return fine, inds, cdf
 
 
+def philox_fill(seed, offset, stream_id, n, normal, device):
+    """The draws the kernels generate under cnerf_cfg.philox, as a tensor: stream 0 u_strat, 1 eps_coarse, 2 u_fine, 3 eps_final."""
+    out = torch.empty(int(n), dtype=torch.float32, device=device)
+    L.check(L.lib().cnerf_philox_fill(int(seed) & 0xFFFFFFFFFFFFFFFF, int(offset) & 0xFFFFFFFF, int(stream_id), int(n), 1 if normal else 0,
+                                      L.ptr(out), _stream()), "cnerf_philox_fill")
+    return out
+
+
 AUX_SHAPES = {
     "coarse_points": lambda B, P, S, n: ((B, P, S, 3), torch.float32),
     "coarse_z": lambda B, P, S, n: ((B, P, S), torch.float32),
@@ -250,7 +260,7 @@ def render_forward(net, fvol, freq, phase, cam2world, img_size, fov, ray_start, 
     dev = cam2world.device
     levels = [_f32(v) for v in as_levels(fvol)] if fvol_is_channel_last else channel_last_levels(fvol)
     cfg = make_cfg(net, B, levels, R, S, fov, ray_start, ray_end, noise_std, hierarchical, white_back,
-                   last_back, clamp_mode)
+                   last_back, clamp_mode, philox=(rng or {}).get("philox"))
     vs = volumes_struct(levels)
     packed = pack_field(net, cfg)
     _, _, ws_bytes = sizes(cfg)
@@ -434,7 +444,7 @@ def _render_backward16(net, o, levels, freq, phase, cam2world, rng, saved, grad_
     B, R, S, hier = o["B"], o["R"], o["S"], o["hier"]
     dev = cam2world.device
     cfg = make_cfg(net, B, levels, R, S, o["fov"], o["ray_start"], o["ray_end"], o["noise_std"], hier,
-                   o["white_back"], o["last_back"], o["clamp_mode"], precision="fp16x3")
+                   o["white_back"], o["last_back"], o["clamp_mode"], precision="fp16x3", philox=rng.get("philox"))
     vs = volumes_struct(levels)
     packed = pack_field(net, cfg)
     packed16 = pack_field_chain16(net, cfg)
@@ -552,9 +562,9 @@ def render_backward(net, o, levels, freq, phase, cam2world, rng, saved, grad_pix
     dev = cam2world.device
     # cfg: precision of the forward (the activation-storing re-run follows it); cfg32: the fp32 gradient chain
     cfg = make_cfg(net, B, levels, R, S, o["fov"], o["ray_start"], o["ray_end"], o["noise_std"], hier,
-                   o["white_back"], o["last_back"], o["clamp_mode"])
+                   o["white_back"], o["last_back"], o["clamp_mode"], philox=rng.get("philox"))
     cfg32 = make_cfg(net, B, levels, R, S, o["fov"], o["ray_start"], o["ray_end"], o["noise_std"], hier,
-                     o["white_back"], o["last_back"], o["clamp_mode"], precision="fp32")
+                     o["white_back"], o["last_back"], o["clamp_mode"], precision="fp32", philox=rng.get("philox"))
     if net.spec.layers[0] == "pfilm":
         c_rs, c_z, f_rs, f_z = saved[:4]
         gc = torch.empty_like(c_rs)

@@ -78,7 +78,16 @@ typedef struct cnerf_cfg {
     int32_t n_levels;     /* feature volumes looked up and concatenated (0 or 1: the single volume V, C) */
     int32_t level_V[CNERF_MAX_LEVELS]; /* side of level i */
     int32_t level_C[CNERF_MAX_LEVELS]; /* channels of level i (multiple of 32); sum = C */
-    int32_t precision;    /* CNERF_PREC_*: arithmetic of the MLP products in the FORWARD kernels (the backward is fp32) */
+    int32_t precision;    /* CNERF_PREC_*: arithmetic of the MLP products in the FORWARD kernels */
+    /* In-kernel random draws (ABI v4).  philox != 0: every draw whose tensor in cnerf_rng is NULL is generated inside the
+     * kernels by Philox4x32-10 with key = philox_seed and counter = (element index in the whole call, stream, philox_offset) --
+     * stream 0 u_strat (B,P,S), 1 eps_coarse (B,P,S), 2 u_fine (B,P,S), 3 eps_final (B,P,S') indexed in sorted order; the noise
+     * streams only when noise_std != 0.  A pure function of (seed, offset, index): the backward entry points given the same cfg
+     * see the same draws, no tensor travels.  Use a fresh philox_offset per call.  philox == 0: NULL tensors mean "no jitter /
+     * no noise" as before (and u_fine is required).  cnerf_philox_fill materialises a stream; oracle/philox.py is its NumPy twin. */
+    uint32_t philox;
+    uint32_t philox_offset;
+    uint64_t philox_seed;
 } cnerf_cfg;
 
 /* Feature volumes, channel-last: level[i] is (B, V_i, V_i, V_i, C_i).  HOST struct of device pointers.  The gradient
@@ -107,7 +116,7 @@ typedef struct cnerf_field_params {
     const float* map_b2;  /* [2*L*H]       */
 } cnerf_field_params;
 
-/* The four random tensors the reference draws, in its draw order; any may be NULL:
+/* The four random tensors the reference draws, in its draw order; any may be NULL (then: cnerf_cfg.philox):
  *   u_strat    (B,P,S)   uniform, stratified jitter          volumetric_rendering.py:106  (NULL -> 0.5, no jitter)
  *   eps_coarse (B,P,S)   normal, density noise, coarse pass  volumetric_rendering.py:39   (NULL -> 0)
  *   u_fine     (B,P,S)   uniform, inverse-CDF draws          volumetric_rendering.py:319  (required if hierarchical)
@@ -157,6 +166,10 @@ typedef struct cnerf_aux {
 } cnerf_aux;
 
 int cnerf_abi_version(void);
+/* out[i] = draw i of stream `stream_id` under (seed, offset): uniform in [0,1) (normal == 0) or standard normal (normal != 0),
+ * exactly what the kernels generate when cnerf_cfg.philox is set.  Replaces torch.rand / torch.randn at
+ * volumetric_rendering.py:39,106,319 for hosts that want the tensors. */
+int cnerf_philox_fill(uint64_t seed, uint32_t offset, uint32_t stream_id, int64_t n, int32_t normal, float* out, void* stream);
 /* Host string describing the last error raised on the calling thread ("" if none). */
 const char* cnerf_last_error(void);
 

@@ -1055,3 +1055,70 @@ def test_fancy_integration_fill_modes(dev):
             want = torch.where(wsum < 0.9, torch.tensor([1.0, 0.0, 0.0]).expand_as(rgb0), rgb0) if mode == "debug" else wsum.expand_as(rgb0)
             near = (wsum - 0.9).abs() < 1e-5            # rays sitting on the threshold may fall either way
             assert ((got.cpu() - want).abs().max(-1)[0][~near.squeeze(-1)] < 1e-5).all(), (mode, last_back)
+
+
+def test_philox_draws_match_numpy_twin(dev):
+    """cnerf_philox_fill (the draws the kernels generate under cnerf_cfg.philox) against oracle/philox.py, itself pinned by the
+    Philox4x32-10 known-answer vectors: uniforms bit for bit, normals to 1e-6 (device logf / cosf vs NumPy's)."""
+    from cnerf_amd import ops
+    from oracle import philox as P
+    seed, off, n = 0x1234567890ABCDEF, 41, 70001
+    for stream in range(4):
+        u = ops.philox_fill(seed, off, stream, n, False, dev).cpu().numpy()
+        assert np.array_equal(u, P.uniform(seed, off, stream, n)), stream
+        g = ops.philox_fill(seed, off, stream, n, True, dev).cpu().numpy()
+        assert np.abs(g - P.normal(seed, off, stream, n)).max() < 2e-6, stream
+    assert not np.array_equal(ops.philox_fill(seed, off + 1, 0, 100, False, dev).cpu().numpy(), P.uniform(seed, off, 0, 100))
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fp16x3"])
+def test_in_kernel_philox_equals_injected_draws(dev, precision):
+    """A render whose four random draws are generated inside the kernels (cnerf_cfg.philox: no tensors) is bit-identical to the
+    render with the same draws injected as tensors (cnerf_philox_fill), forward and -- for the gradients -- backward: stratified
+    jitter in the field kernels, density noise and inverse-CDF draws in the per-ray kernels, the re-computed positions of the
+    backward.  Ragged size, several images, noise on."""
+    import cnerf_amd
+    from cnerf_amd import ops
+    from cnerf_amd.generators import ImplicitGenerator3d
+    torch.manual_seed(9)
+    B, R, S, V, H = 3, 7, 11, 9, 64
+    P_ = R * R
+    gen = ImplicitGenerator3d("SHORTSIREN_FG", 32, 32, 4, H).to(dev)
+    gen.set_device(dev)
+    gen.siren.precision = precision
+    gen.train()
+    with torch.no_grad():
+        gen.siren.final_layer.weight[3] *= 20
+    fvol, glob = torch.randn(B, 32, V, V, V, device=dev), torch.randn(B, 32, device=dev)
+    cam = torch.eye(4, device=dev).unsqueeze(0).repeat(B, 1, 1).contiguous()
+    cam[:, 2, 3] = -1.0
+    cam[:, 0, 3] = torch.linspace(-0.2, 0.2, B, device=dev)
+    seed, off = 987654321, 5
+    inj = {"u_strat": ops.philox_fill(seed, off, 0, B * P_ * S, False, dev), "eps_coarse": ops.philox_fill(seed, off, 1, B * P_ * S, True, dev),
+           "u_fine": ops.philox_fill(seed, off, 2, B * P_ * S, False, dev), "eps_final": ops.philox_fill(seed, off, 3, B * P_ * 2 * S, True, dev)}
+    outs = []
+    for rng in ({"philox": (seed, off)}, inj):
+        fv, gl = fvol.clone().requires_grad_(True), glob.clone().requires_grad_(True)
+        gen.zero_grad()
+        aux = {}
+        px, dp = gen((fv, gl), cam, R, 49.13, 0.25, 1.95, S, True, clamp_mode="softplus", nerf_noise=0.4, white_back=True, _rng=rng, _aux=aux)
+        (px.square().mean() + dp.mean()).backward()
+        outs.append((px.detach().clone(), dp.detach().clone(), aux["coarse_z"].clone(), aux["fine_z"].clone(), fv.grad.clone(), gl.grad.clone(),
+                     gen.siren.network[0].layer.weight.grad.clone()))
+    a, b = outs
+    for i in range(4):
+        assert torch.equal(a[i], b[i]), i                       # pixels, depth, jittered depths, resampled depths: bit for bit
+    for i in range(4, 7):                                        # gradients: the volume scatter's atomics reorder sums at the 1e-7 level
+        assert (a[i] - b[i]).abs().max().item() <= 1e-5 * b[i].abs().max().item(), i
+    # and the module-level switch: two forwards draw different numbers, a re-seeded twin the same ones
+    gen.eval()
+    gen.rng_mode = "philox"
+    torch.cuda.manual_seed(77)
+    with torch.no_grad():
+        p1, _ = gen((fvol, glob), cam, R, 49.13, 0.25, 1.95, S, True, clamp_mode="relu", nerf_noise=0.0)
+        p2, _ = gen((fvol, glob), cam, R, 49.13, 0.25, 1.95, S, True, clamp_mode="relu", nerf_noise=0.0)
+    assert not torch.equal(p1, p2)
+    gen._philox_calls -= 2
+    with torch.no_grad():
+        p3, _ = gen((fvol, glob), cam, R, 49.13, 0.25, 1.95, S, True, clamp_mode="relu", nerf_noise=0.0)
+    assert torch.equal(p1, p3)

@@ -109,3 +109,19 @@ def test_unknown_variant_and_dropout():
     gen.train()
     with pytest.raises(NotImplementedError):
         gen.siren.check_supported()
+
+
+def test_philox_known_answers():
+    """oracle/philox.py against the known-answer vectors of Philox4x32-10 (Random123 kat_vectors): zeros, all ones, and the
+    digits-of-pi counter / key."""
+    from oracle import philox as P
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff, 0xffffffff), (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        got = tuple(int(x) for x in P.philox4x32_10(*ctr, *key))
+        assert got == want, (ctr, key, [hex(g) for g in got])
+    u = P.uniform(1234, 7, 0, 100000)
+    assert u.min() >= 0 and u.max() < 1 and abs(u.mean() - 0.5) < 5e-3 and np.all(u * 2 ** 24 == np.round(u * 2 ** 24))
+    n = P.normal(1234, 7, 1, 200000)
+    assert abs(n.mean()) < 1e-2 and abs(n.std() - 1) < 1e-2 and np.isfinite(n).all()
