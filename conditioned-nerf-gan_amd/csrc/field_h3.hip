@@ -181,6 +181,7 @@ struct ActStore {
     _Float16* blk_h;
     _Float16* blk_c;
     bool live;
+    float pv, pc;            // balanced epilogue: sine (and cosine) of a pair's first element, computed one k-chunk before the second
 };
 constexpr int STORE_NONE = 0, STORE_F32 = 1, STORE_TB16 = 2;
 
@@ -194,22 +195,38 @@ __device__ __forceinline__ float half_hi(uint32_t u) { return (float)__builtin_b
 
 // RESID (second matrix of a residual block, siren.py:218-230): the slot the result goes to still holds the block's input
 // x as its two fp16 parts; x = hi + lo is added to W2 y + b2 before the sine, and the slot is overwritten.
-template <int STORE, bool RESID>
+// PHASE 0: both elements at once (layer 0, tails).  PHASE 1: only the pair's first element -> st.pv / st.pc; PHASE 2: the second
+// element and everything that needs both (stores, split) -- the two halves of the balanced epilogue, one k-chunk apart, so
+// that every chunk of the MFMA loop carries about the same number of vector instructions (an un-split pair every second
+// chunk puts ~9 vector slots into each of three MFMA gaps and none into the next three).
+template <int STORE, bool RESID, int PHASE = 0>
 __device__ __forceinline__ void film_split_pair(const f32x16& acc, float inv_s, const FilmPair& f, int t, int h, int r, Split2* out2,
                                                 ActStore& st) {
-    float a0 = __builtin_fmaf(acc[r], inv_s, f.bs[0]), a1 = __builtin_fmaf(acc[r + 1], inv_s, f.bs[1]);
+    float a0 = 0.0f, a1 = 0.0f;
+    if (PHASE != 2) a0 = __builtin_fmaf(acc[r], inv_s, f.bs[0]);
+    if (PHASE != 1) a1 = __builtin_fmaf(acc[r + 1], inv_s, f.bs[1]);
     if (RESID) {
         const uint32_t xh = out2[r >> 3].p[0][(r & 7) >> 1], xl = PARTS == 2 ? out2[r >> 3].p[PARTS - 1][(r & 7) >> 1] : 0u;
-        a0 = (half_lo(xh) + half_lo(xl)) + a0;
-        a1 = (half_hi(xh) + half_hi(xl)) + a1;
+        if (PHASE != 2) a0 = (half_lo(xh) + half_lo(xl)) + a0;
+        if (PHASE != 1) a1 = (half_hi(xh) + half_hi(xl)) + a1;
     } else {
-        a0 = f.fr[0] * a0 + f.ph[0];
-        a1 = f.fr[1] * a1 + f.ph[1];
+        if (PHASE != 2) a0 = f.fr[0] * a0 + f.ph[0];
+        if (PHASE != 1) a1 = f.fr[1] * a1 + f.ph[1];
     }
-    float v0, v1;
+    float v0 = 0.0f, v1 = 0.0f;
+    if (PHASE == 1) {
+        if (STORE) sincos_2pi_reduced_hw(a0, st.pv, st.pc);
+        else st.pv = sin_2pi_reduced_hw(a0);
+        return;
+    }
     if (STORE) {
         float c0, c1;
-        sincos_2pi_reduced_hw(a0, v0, c0);
+        if (PHASE == 2) {
+            v0 = st.pv;
+            c0 = st.pc;
+        } else {
+            sincos_2pi_reduced_hw(a0, v0, c0);
+        }
         sincos_2pi_reduced_hw(a1, v1, c1);
         if ((r & 2) == 0) {
             st.ks[0] = v0;
@@ -228,7 +245,7 @@ __device__ __forceinline__ void film_split_pair(const f32x16& acc, float inv_s, 
             *reinterpret_cast<u32x2_*>(st.blk_c + (t * 4 + (r >> 2)) * 256) = u32x2_{pk_f16(st.kc[0], st.kc[1]), pk_f16(c0, c1)};
         }
     } else {
-        v0 = sin_2pi_reduced_hw(a0);
+        v0 = PHASE == 2 ? st.pv : sin_2pi_reduced_hw(a0);
         v1 = sin_2pi_reduced_hw(a1);
     }
     Split2& d = out2[r >> 3];
@@ -261,6 +278,18 @@ __device__ __forceinline__ void film_split(const f32x16& acc, float inv_s, const
 // together, the barrier is not where the time goes.  Default: two slots.
 #ifndef CNERF_H3_SLOTS
 #define CNERF_H3_SLOTS 2
+#endif
+// Epilogue placement inside the MFMA loop of a hidden layer: BALANCE splits every element pair over two k-chunks (about 13
+// vector slots in every chunk instead of ~26 in every second one); VPM = vector instructions the scheduler may place behind
+// each MFMA.  Measured (scripts/ab_h3.sh, field kernel per launch at the bench shape): unbalanced / VPM 7: 11.21 ms; balanced with
+// VPM 4 / 5 / 6 / 7: 11.36 / 11.38 / 11.47 / 11.52 ms (single-pass kernel 7.02 -> 7.47) -- the distribution of the vector work
+// over the gaps is not what limits this kernel (total vector issue + MFMA issue of the one wave per SIMD is: PMC table in
+// profiles/r02_kernel_counters.md).  Default: unbalanced.
+#ifndef CNERF_H3_BALANCE
+#define CNERF_H3_BALANCE 0
+#endif
+#ifndef CNERF_H3_VPM
+#define CNERF_H3_VPM 7
 #endif
 
 template <int NT>
@@ -574,19 +603,36 @@ __global__ __launch_bounds__(256) void field_h3_kernel(FieldArgs a) {
             constexpr bool RESID = decltype(resid_tag)::value;
             const float inv_s = lds_inv_s[m];
             f32x16 acc_prev;
-            FilmPair fp;
+            FilmPair fp, fp_done;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const f16x8* unit = unit_begin(!PAIRED || (t & 1));   // PAIRED: unit 1 + (m-1) NT + t of the tile, even iff t is odd
                 f32x16 acc;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-                acc = h3_tile_from_lds<NT, 7>(unit, in, acc, lane, [&](int c) {
+                acc = h3_tile_from_lds<NT, CNERF_H3_VPM>(unit, in, acc, lane, [&](int c) {
+#if CNERF_H3_BALANCE
+                    // epilogue of tile t-1, half a pair per chunk: chunk 2p fetches pair p's FiLM values (and finishes pair p-1),
+                    // chunk 2p+1 does pair p's first element; the last pair is finished behind the loop
+                    if (t > 0 && c < 16) {
+                        if (!(c & 1)) {
+                            if (c >= 2) film_split_pair<STORE, RESID, 2>(acc_prev, inv_s, fp_done, t - 1, h, c - 2, &out[2 * (t - 1)], st);
+                            fp = film_pair_load(bias, fr_l, ph_l, t - 1, h, c);
+                        } else {
+                            film_split_pair<STORE, RESID, 1>(acc_prev, inv_s, fp, t - 1, h, c - 1, &out[2 * (t - 1)], st);
+                            fp_done = fp;
+                        }
+                    }
+#else
                     if (t > 0 && c < 16) {                     // epilogue of tile t-1, one pair of elements per two chunks
                         if (!(c & 1)) fp = film_pair_load(bias, fr_l, ph_l, t - 1, h, c);
                         else film_split_pair<STORE, RESID>(acc_prev, inv_s, fp, t - 1, h, c - 1, &out[2 * (t - 1)], st);
                     }
+#endif
                 });
+#if CNERF_H3_BALANCE
+                if (t > 0) film_split_pair<STORE, RESID, 2>(acc_prev, inv_s, fp_done, t - 1, h, (KCH < 16 ? KCH : 16) - 2, &out[2 * (t - 1)], st);
+#endif
                 if (t > 0 && KCH < 16) {                       // narrow networks: the rest of tile t-1's elements
 #pragma unroll
                     for (int r = KCH; r < 16; r += 2)
