@@ -77,6 +77,7 @@ class GanTrainer:
         self.optimizer_D = adam(self.discriminator_ddp, metadata["disc_lr"])
         self.alpha = 1.0
         self.losses = {"d": [], "g": [], "photo": []}
+        self._z = {}            # chunk index -> encoder output kept between the D and the G pass of one step
         self.last = {}          # diagnostics of the most recent step: loss terms and pre-clip gradient norms
         self.render_rng = None  # test hook: callable(chunk_index, phase) -> dict of injected draws for that render
 
@@ -91,7 +92,9 @@ class GanTrainer:
         self.metadata["nerf_noise"] = max(0.0, 1.0 - step / 5000.0)
 
     def _render(self, voxels, cams, chunk=0, phase="g"):
-        z = self.encoder_ddp(voxels)
+        z = self._z.get(chunk) if phase == "d" else self._z.pop(chunk, None)      # encoder output kept by step() (see there)
+        if z is None:
+            z = self.encoder_ddp(voxels)
         extra = {"_rng": self.render_rng(chunk, phase)} if self.render_rng is not None else {}
         return self.generator_ddp(z, cams, **self.metadata, **extra)
 
@@ -179,10 +182,26 @@ class GanTrainer:
             m.zero_grad(set_to_none=True)
 
     def step(self, sample):
+        """One D step and one G step on `sample`.  Both passes render the same voxel grids and the encoder's parameters do not
+        change in between (the D step only updates the discriminator), so with metadata["reuse_encoder_output"] (default on)
+        the encoder runs ONCE per accumulation chunk, with its autograd graph, before the D step: the D step's no-grad renders
+        read that output, the G step back-propagates through it.  Same numbers as the reference's recomputation
+        (utils.py:653-657,778-781), one encoder forward per chunk less (64 ms of a 307 ms step at 128x128x64, batch 8).  Under
+        DDP the last chunk is left out: its forward must be the one directly followed by the backward that all-reduces."""
         self.set_alpha()
+        self._z = {}
+        if self.metadata["enable_discriminator"] and self.metadata.get("reuse_encoder_output", True):
+            voxels = sample["voxel"].to(self.device)
+            chunks = self._chunks(voxels.shape[0])
+            for i, c in enumerate(chunks):
+                if self.ddp and i == len(chunks) - 1:
+                    continue
+                with (self.encoder_ddp.no_sync() if self.ddp else contextlib.nullcontext()):
+                    self._z[i] = self.encoder_ddp(voxels[c])
         if self.metadata["enable_discriminator"]:
             self.train_discriminator(sample)
         self.train_generator(sample)
+        self._z = {}
         self.generator.step += 1
         self.discriminator.step += 1
 
