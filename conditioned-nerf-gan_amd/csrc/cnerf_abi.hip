@@ -523,7 +523,8 @@ int cnerf_backward_bytes(const cnerf_cfg* cfg, size_t* packed_t) {
     const size_t NT = cfg->H / 32, tile = 4 * 64 * 4;
     size_t fl = NT * 2 * 64;                                  // head^T
     for (int l = cfg->L - 1; l >= 1; --l) fl += (cfg->layer_kind[l] == CNERF_LAYER_RES ? 2 : 1) * NT * NT * tile;
-    fl += (size_t)packed_layout(cfg).n_in * NT * tile;       // layer 0 transposed: one 32-row output tile per input tile
+    if (cfg->layer_kind[0] != CNERF_LAYER_PFILM)             // (per-point FiLM: layer 0 reads the sample position, no gradient)
+        fl += (size_t)packed_layout(cfg).n_in * NT * tile;   // layer 0 transposed: one 32-row output tile per input tile
     if (packed_t) *packed_t = align256(fl * sizeof(float));
     return CNERF_OK;
 }
@@ -531,7 +532,6 @@ int cnerf_backward_bytes(const cnerf_cfg* cfg, size_t* packed_t) {
 int cnerf_pack_field_transposed(const cnerf_cfg* cfg, const cnerf_field_params* p, float* packed_t, void* stream_) {
     g_err[0] = 0;
     if (int rc = check_cfg(cfg, false)) return rc;
-    if (cfg->layer_kind[0] == CNERF_LAYER_PFILM) return fail(CNERF_ENOSYS, "backward of the per-point FiLM family is not implemented");
     if (!p || !packed_t) return fail(CNERF_EINVAL, "pack_field_transposed: NULL argument");
     hipStream_t stream = (hipStream_t)stream_;
     const int H = cfg->H, NT = H / 32;
@@ -550,6 +550,7 @@ int cnerf_pack_field_transposed(const cnerf_cfg* cfg, const cnerf_field_params* 
         if (hipError_t e = launch_pack_matrix_t(p->w[l], H, H, NT, dst, stream)) return hip_fail(e, "pack_matrix_t");
         dst += (size_t)NT * NT * tile;
     }
+    if (cfg->layer_kind[0] == CNERF_LAYER_PFILM) return CNERF_OK;      // head^T and W_l^T of layers L-1..1 only
     if (!p->w[0]) return fail(CNERF_EINVAL, "pack_field_transposed: layer 0 weight is NULL");
     const PackedLayout pl = packed_layout(cfg);
     if (hipError_t e = launch_pack_matrix_t(p->w[0], H, pl.k0, pl.n_in, dst, stream)) return hip_fail(e, "pack_matrix_t");
@@ -579,7 +580,6 @@ int cnerf_field_backward(const cnerf_cfg* cfg, int32_t pass, int32_t image0, int
                          float* act_c, float* act_g, float* act_go, const cnerf_grad_volumes* grad_vols, void* stream_) {
     g_err[0] = 0;
     if (int rc = check_cfg(cfg, true)) return rc;
-    if (cfg->layer_kind[0] == CNERF_LAYER_PFILM) return fail(CNERF_ENOSYS, "backward of the per-point FiLM family is not implemented");
     if (image0 < 0 || n_images < 1 || image0 + n_images > cfg->B) return fail(CNERF_EINVAL, "field_backward: image range out of [0,B)");
     if (pass < 0 || pass > 2) return fail(CNERF_EINVAL, "field_backward: pass must be 0 (coarse), 1 (fine) or 2 (explicit points)");
     if (!vols || !packed || !packed_t || !cam2world || !grad_rgb_sigma || !saved_rgb_sigma || !act_feat || !act_h || !act_c ||

@@ -450,7 +450,10 @@ __global__ __launch_bounds__(256) void field_tile_kernel(FieldArgs a) {
 // come per POINT from a mapping MLP of the looked-up feature:  m = LeakyReLU_0.2(Wm1 feat + bm1) (256 wide),
 // [freq | phase] = Wm2 m + bm2 (2*L*H wide), freq = freq*15+30.  The 2*L*H mapping outputs are never materialised: for
 // output tile t of layer l the kernel runs three accumulations -- W_l x, Wm2[freq rows] m, Wm2[phase rows] m -- and
-// combines them in the epilogue.  Forward only (its backward is not written: CNERF_ENOSYS).
+// combines them in the epilogue.
+// STORE (the activation-storing re-run of the backward pass, see field_pw_backward_kernel): the looked-up feature, m, and per
+// layer four rows per point -- y = sin(arg), cos(arg), cos(arg) * freq, cos(arg) * 15 * pre -- i.e. d arg / d (phase, pre, raw
+// frequency output) already multiplied into the cosine, so that the gradient chain is three multiplies per element.
 // Packed stream: Wm1 (8 x 1 tiles) | per layer: W_l (NT x KT), Wm2 freq rows (NT x 8), Wm2 phase rows (NT x 8) | head.
 // Bias stream:   bm1 (256) | per layer: b_l (H), bm2 freq slice (H), bm2 phase slice (H) | head bias (4).
 // ---------------------------------------------------------------------------------------------------------------
@@ -473,11 +476,12 @@ __device__ __forceinline__ f32x16 mfma_accumulate(const f32x4* __restrict__ wp, 
     return acc;
 }
 
-template <int NT, int KT>
+template <int NT, int KT, bool STORE>
 __device__ __forceinline__ void pfilm_layer(const f32x4* __restrict__ w_main, const f32x4* __restrict__ w_freq,
                                             const f32x4* __restrict__ w_phase, const float* __restrict__ b_main,
                                             const float* __restrict__ b_freq, const float* __restrict__ b_phase,
-                                            const f32x16* x, const f32x16* m, f32x16* y, int lane, int h) {
+                                            const f32x16* x, const f32x16* m, f32x16* y, int lane, int h,
+                                            float* __restrict__ row_y, float* __restrict__ row_c, size_t slab) {
     constexpr size_t TILE4 = 4 * 64;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -485,13 +489,33 @@ __device__ __forceinline__ void pfilm_layer(const f32x4* __restrict__ w_main, co
         f32x16 ph = mfma_accumulate<8>(w_phase + (size_t)t * 8 * TILE4, m, load_chan16(b_phase, t, h), lane);
         f32x16 pre = mfma_accumulate<KT>(w_main + (size_t)t * KT * TILE4, x, load_chan16(b_main, t, h), lane);
         f32x16 o;
+        if (STORE) {
+            f32x16 cs, cf, cp;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[r] = sin_pi_reduced((fr[r] * 15.0f + 30.0f) * pre[r] + ph[r]);
+            for (int r = 0; r < 16; ++r) {
+                const float f = fr[r] * 15.0f + 30.0f;
+                float sn, c_;
+                sincos_pi_reduced(f * pre[r] + ph[r], sn, c_);
+                o[r] = sn;
+                cs[r] = c_;
+                cf[r] = c_ * f;
+                cp[r] = c_ * (15.0f * pre[r]);
+            }
+            if (row_y) {                       // (padded lanes of an image's last tile shadow its last point: they do not store)
+                store_tile_rows(row_y, t, h, o);
+                store_tile_rows(row_c, t, h, cs);
+                store_tile_rows(row_c + slab, t, h, cf);
+                store_tile_rows(row_c + 2 * slab, t, h, cp);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[r] = sin_pi_reduced((fr[r] * 15.0f + 30.0f) * pre[r] + ph[r]);
+        }
         y[t] = o;
     }
 }
 
-template <int NT>
+template <int NT, bool STORE>
 __global__ __launch_bounds__(256) void field_pw_kernel(FieldArgs a) {
     const int lane = threadIdx.x & 63;
     const int j = lane & 31, h = lane >> 5;
@@ -505,6 +529,12 @@ __global__ __launch_bounds__(256) void field_pw_kernel(FieldArgs a) {
         const long long nn = valid ? n : (a.n_per_image - 1);
         float px, py, pz;
         tile_point(a, b, nn, valid, h, true, px, py, pz);
+        // activation store (STORE): act_h = L slabs (n,H) of y, then m (n,256); act_c = 3L slabs (n,H): cos, cos*freq, cos*15*pre
+        const size_t gpt = (size_t)b * a.n_per_image + nn;
+        const size_t slab = (size_t)a.act_points * H;
+        const bool st = STORE && valid;
+        float* row_y = st ? a.act_h + gpt * H : nullptr;
+        float* row_c = st ? a.act_c + gpt * H : nullptr;
 
         const f32x4* wp = reinterpret_cast<const f32x4*>(a.packed);
         const float* bias = a.bias;
@@ -512,6 +542,7 @@ __global__ __launch_bounds__(256) void field_pw_kernel(FieldArgs a) {
         Act<8> m;
         {
             const f32x16 feat = input_tile(a, b, 0, px, py, pz, h);
+            if (st) store_tile_rows(a.act_feat + gpt * 32, 0, h, feat);
 #pragma unroll
             for (int t = 0; t < 8; ++t) m.v[t] = load_chan16(bias, t, h);
             layer0_accumulate<8>(wp, 1, 0, feat, m.v, lane);
@@ -519,6 +550,11 @@ __global__ __launch_bounds__(256) void field_pw_kernel(FieldArgs a) {
             for (int t = 0; t < 8; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) m.v[t][r] = m.v[t][r] > 0.0f ? m.v[t][r] : m.v[t][r] * 0.2f;
+            if (st) {
+                float* row_m = a.act_h + (size_t)a.L * slab + gpt * 256;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) store_tile_rows(row_m, t, h, m.v[t]);
+            }
             wp += 8 * TILE4;
             bias += 256;
         }
@@ -536,18 +572,22 @@ __global__ __launch_bounds__(256) void field_pw_kernel(FieldArgs a) {
                 const f32x4* w_main = wp;
                 const f32x4* w_freq = w_main + (size_t)NT * 1 * TILE4;
                 const f32x4* w_phase = w_freq + (size_t)NT * 8 * TILE4;
-                pfilm_layer<NT, 1>(w_main, w_freq, w_phase, bias, bias + H, bias + 2 * H, &xyz, m.v, x.v, lane, h);
+                pfilm_layer<NT, 1, STORE>(w_main, w_freq, w_phase, bias, bias + H, bias + 2 * H, &xyz, m.v, x.v, lane, h, row_y, row_c, slab);
                 wp = w_phase + (size_t)NT * 8 * TILE4;
             } else {
                 const f32x4* w_main = wp;
                 const f32x4* w_freq = w_main + (size_t)NT * NT * TILE4;
                 const f32x4* w_phase = w_freq + (size_t)NT * 8 * TILE4;
-                pfilm_layer<NT, NT>(w_main, w_freq, w_phase, bias, bias + H, bias + 2 * H, x.v, m.v, y.v, lane, h);
+                pfilm_layer<NT, NT, STORE>(w_main, w_freq, w_phase, bias, bias + H, bias + 2 * H, x.v, m.v, y.v, lane, h, row_y, row_c, slab);
                 wp = w_phase + (size_t)NT * 8 * TILE4;
 #pragma unroll
                 for (int t = 0; t < NT; ++t) x.v[t] = y.v[t];
             }
             bias += 3 * H;
+            if (st) {
+                row_y += slab;
+                row_c += 3 * slab;
+            }
         }
         // head
         const f32x4 acc = head_forward<NT>(wp, bias, x.v, lane);
@@ -626,6 +666,97 @@ __device__ __forceinline__ void bwd_activation(f32x16* g, const float* __restric
     }
 }
 
+// go' = d loss / d head pre-activation (stored), g = W_head^T go'; returns the transposed-weight stream behind the head
+template <int NT>
+__device__ __forceinline__ const float* head_backward(const FieldArgs& a, size_t gpt, bool valid, int h, int lane, f32x16* g) {
+    f32x4 go = *reinterpret_cast<const f32x4*>(a.grad_out + gpt * 4);
+    if (!valid) go = f32x4{0.f, 0.f, 0.f, 0.f};        // padded lanes shadow the last point: they must add nothing
+    if (a.flags & CNERF_F_SIGMOID_RGB) {
+        const f32x4 so = *reinterpret_cast<const f32x4*>(a.saved_out + gpt * 4);
+        go[0] = go[0] * (so[0] * (1.0f - so[0]));
+        go[1] = go[1] * (so[1] * (1.0f - so[1]));
+        go[2] = go[2] * (so[2] * (1.0f - so[2]));
+    }
+    if (valid && h == 0) *reinterpret_cast<f32x4*>(a.act_go + gpt * 4) = go;
+    // packed_t layout: [head^T: NT tiles x 2 k-steps x 64 lanes floats, padded to float4 groups][layers L..1 transposed]
+    const float* wt = a.packed_t;
+    const float b0 = h ? go[1] : go[0], b1 = h ? go[3] : go[2];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wt[(t * 2 + 0) * 64 + lane], b0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wt[(t * 2 + 1) * 64 + lane], b1, acc, 0, 0, 0);
+        g[t] = acc;
+    }
+    return wt + (size_t)NT * 2 * 64;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Gradient chain of the per-point FiLM family (TALLSIREN) over the rows field_pw_kernel<NT, true> stored.  Per layer, from
+// g_y = d loss / d y_l:   g_phase = g_y cos,  g_pre = g_y (cos freq),  g_rawfreq = g_y (cos 15 pre)   (three stored rows),
+// g_y_{l-1} = W_l^T g_pre (MFMA on the transposed pack).  act_g: L slabs (n,H) of g_pre -- dW_l = g_pre^T y_{l-1}, db_l its
+// column sums: cnerf_weight_grad -- followed by G (n, 2 L H) = [g_rawfreq of layers 0..L-1 | g_phase of layers 0..L-1], i.e.
+// d loss / d (output of the mapping network's second Linear) row by row in that Linear's own output order: its weight
+// gradient G^T m and the gradient G Wm2 that continues into the mapping MLP, the looked-up feature and the volume are
+// plain GEMMs over this buffer, left to the caller (library GEMMs + cnerf_scatter_features).  The sample positions carry
+// no gradient (generators.py:57,111), so the chain stops at layer 0.
+// ---------------------------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(256) void field_pw_backward_kernel(FieldArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int j = lane & 31, h = lane >> 5;
+    constexpr int H = NT * 32;
+    constexpr size_t TILE4 = 4 * 64;
+    const TileRange tr = tile_range(a.total_tiles);
+    for (long long tile = tr.begin; tile < tr.end; tile += tr.stride) {
+        const int b = (int)(tile / a.tiles_per_image);
+        const long long n = (tile - (long long)b * a.tiles_per_image) * 32 + j;
+        const bool valid = n < a.n_per_image;
+        const long long nn = valid ? n : (a.n_per_image - 1);
+        const size_t gpt = (size_t)b * a.n_per_image + nn;
+        const size_t slab = (size_t)a.act_points * H;
+        Act<NT> g, g2;
+        const f32x4* wp = reinterpret_cast<const f32x4*>(head_backward<NT>(a, gpt, valid, h, lane, g.v));
+        float* row_G = a.act_g + (size_t)a.L * slab + gpt * (size_t)(2 * a.L * H);
+        for (int l = a.L - 1; l >= 0; --l) {
+            const float* rc = a.act_c + (size_t)(3 * l) * slab + gpt * H;
+            float* row_gp = a.act_g + (size_t)l * slab + gpt * H;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                f32x16 gph, gpre, gfr;
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const int o = 32 * t + 8 * gq + 4 * h;
+                    const f32x4 c = *reinterpret_cast<const f32x4*>(rc + o);
+                    const f32x4 cf = *reinterpret_cast<const f32x4*>(rc + slab + o);
+                    const f32x4 cp = *reinterpret_cast<const f32x4*>(rc + 2 * slab + o);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float gy = g.v[t][4 * gq + e];
+                        gph[4 * gq + e] = gy * c[e];
+                        gpre[4 * gq + e] = gy * cf[e];
+                        gfr[4 * gq + e] = gy * cp[e];
+                    }
+                }
+                if (valid) {
+                    store_tile_rows(row_gp, t, h, gpre);
+                    store_tile_rows(row_G + (size_t)l * H, t, h, gfr);
+                    store_tile_rows(row_G + (size_t)(a.L + l) * H, t, h, gph);
+                }
+                g.v[t] = gpre;
+            }
+            if (l > 0) {
+                bwd_matrix<NT, NT>(wp, g.v, g2.v, lane);
+                wp += (size_t)NT * NT * TILE4;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) g.v[t] = g2.v[t];
+            }
+        }
+    }
+}
+
 template <int NT, bool HAS_RES>
 __global__ __launch_bounds__(256) void field_backward_kernel(FieldArgs a) {
     __shared__ float s_g[4][32][33];     // per wave: g_feat [point][channel] (padded)
@@ -646,33 +777,8 @@ __global__ __launch_bounds__(256) void field_backward_kernel(FieldArgs a) {
         const size_t act_layer = (size_t)a.act_points * H;
 
         // ---- head backward -------------------------------------------------------------------------------------------
-        f32x4 go = *reinterpret_cast<const f32x4*>(a.grad_out + gpt * 4);
-        if (!valid) go = f32x4{0.f, 0.f, 0.f, 0.f};        // padded lanes shadow the last point: they must add nothing
-        if (a.flags & CNERF_F_SIGMOID_RGB) {
-            const f32x4 so = *reinterpret_cast<const f32x4*>(a.saved_out + gpt * 4);
-            go[0] = go[0] * (so[0] * (1.0f - so[0]));
-            go[1] = go[1] * (so[1] * (1.0f - so[1]));
-            go[2] = go[2] * (so[2] * (1.0f - so[2]));
-        }
-        if (valid && h == 0) *reinterpret_cast<f32x4*>(a.act_go + gpt * 4) = go;
-
         Act<NT> g, g2;
-        // packed_t layout: [head^T: NT tiles x 2 k-steps x 64 lanes floats, padded to float4 groups][layers L..1 transposed]
-        const float* wt = a.packed_t;
-        {
-            const float b0 = h ? go[1] : go[0], b1 = h ? go[3] : go[2];
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                f32x16 acc;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wt[(t * 2 + 0) * 64 + lane], b0, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wt[(t * 2 + 1) * 64 + lane], b1, acc, 0, 0, 0);
-                g.v[t] = acc;
-            }
-            wt += (size_t)NT * 2 * 64;
-        }
-        const f32x4* wp = reinterpret_cast<const f32x4*>(wt);
+        const f32x4* wp = reinterpret_cast<const f32x4*>(head_backward<NT>(a, gpt, valid, h, lane, g.v));
         const float* ones = a.bias + a.bias_floats;
         int film_idx = 0, sub = -1;       // sub: index of the activation slab (a residual block owns two)
         for (int l = 0; l < a.L; ++l) {
@@ -857,7 +963,22 @@ static bool has_res(const FieldArgs& a) {
     return res;
 }
 
+template <int NT>
+static hipError_t launch_field_pw_backward_nt(const FieldArgs& a, hipStream_t stream) {
+    const int blocks = field_grid((const void*)field_pw_backward_kernel<NT>, a.total_tiles);
+    hipLaunchKernelGGL((field_pw_backward_kernel<NT>), dim3(blocks), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
 hipError_t launch_field_backward(const FieldArgs& a, int H, hipStream_t stream) {
+    if (a.layer_kind[0] == CNERF_LAYER_PFILM) {
+        switch (H / 32) {
+            case 2: return launch_field_pw_backward_nt<2>(a, stream);
+            case 4: return launch_field_pw_backward_nt<4>(a, stream);
+            case 8: return launch_field_pw_backward_nt<8>(a, stream);
+            default: return hipErrorInvalidValue;
+        }
+    }
     const bool res = has_res(a);
     switch (H / 32) {
         case 2: return res ? launch_field_backward_nt<2, true>(a, stream) : launch_field_backward_nt<2, false>(a, stream);
@@ -886,11 +1007,16 @@ static hipError_t launch_field_nt(const FieldArgs& a, hipStream_t stream) {
     return a.act_h ? launch_field_tile<NT, HAS_RES, true>(a, stream) : launch_field_tile<NT, HAS_RES, false>(a, stream);
 }
 
+template <int NT, bool STORE>
+static hipError_t launch_field_pw(const FieldArgs& a, hipStream_t stream) {
+    const int blocks = field_grid((const void*)field_pw_kernel<NT, STORE>, a.total_tiles);
+    hipLaunchKernelGGL((field_pw_kernel<NT, STORE>), dim3(blocks), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
 template <int NT>
 static hipError_t launch_field_pw_nt(const FieldArgs& a, hipStream_t stream) {
-    const int blocks = field_grid((const void*)field_pw_kernel<NT>, a.total_tiles);
-    hipLaunchKernelGGL(field_pw_kernel<NT>, dim3(blocks), dim3(256), 0, stream, a);
-    return hipGetLastError();
+    return a.act_h ? launch_field_pw<NT, true>(a, stream) : launch_field_pw<NT, false>(a, stream);
 }
 
 hipError_t launch_field(const FieldArgs& a, int H, hipStream_t stream) {

@@ -170,7 +170,8 @@ class PointwiseFiLMLayer(_LinearSine):
 class TALLSIREN(FieldNetwork):
     """pi-GAN style field (siren.py:232-331): input = world xyz, eight FiLM layers whose frequencies / phases come per
     POINT from a mapping MLP of the looked-up feature (z is the bare feature volume, z_dim = its channel count).
-    Parameters, names and initialisation mirror the reference so its checkpoints load.  Forward only on the GPU so far."""
+    Parameters, names and initialisation mirror the reference so its checkpoints load.  fp32 only (forward: field_pw_kernel;
+    backward: storing forward + field_pw_backward_kernel, ops._pfilm_backward)."""
     variant = "TALLSIREN"
     spec = FieldSpec(("pfilm",) * 8, 25, False, False, False, "xyz")
 

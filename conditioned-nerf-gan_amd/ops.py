@@ -324,54 +324,75 @@ DEBUG_CAPTURE = None            # set to a dict to capture the backward's chunk 
 ACT_BUDGET_BYTES = 48 << 30     # activation / gradient chunk buffers of the backward (288 GB HBM per GPU)
 
 
-PFILM_CHUNK_POINTS = 1 << 17    # points per chunk of the per-point-FiLM backward (~60 KB of activations per point)
-
-
-def _pfilm_mlp(spec, ps, feat, pts, H):
-    """TALLSIREN on looked-up features (siren.py:232-331): m = LeakyReLU_0.2(Wm1 feat + bm1); (freq | phase) = Wm2 m + bm2,
-    freq * 15 + 30; x = xyz; x = sin(freq_l * (W_l x + b_l) + phase_l) per layer; head.  Plain torch ops: the backward
-    of this family runs its dense algebra as library GEMMs."""
-    nl = len(spec.layers)
-    m = F.leaky_relu(F.linear(feat, ps[0], ps[1]), 0.2)
-    fo = F.linear(m, ps[2], ps[3])
-    half = fo.shape[-1] // 2
-    freq, phase = fo[..., :half] * 15 + 30, fo[..., half:]
-    x = pts
-    for l in range(nl):
-        x = torch.sin(freq[..., l * H:(l + 1) * H] * F.linear(x, ps[4 + 2 * l], ps[5 + 2 * l]) + phase[..., l * H:(l + 1) * H])
-    out = F.linear(x, ps[4 + 2 * nl], ps[5 + 2 * nl])
-    if spec.sigmoid_rgb:
-        out = torch.cat([torch.sigmoid(out[..., :3]), out[..., 3:]], -1)
-    return out
-
-
-def _pfilm_backward(net, cfg, levels, saved, gc, gf, hier):
-    """Field gradients of the per-point FiLM family: per chunk of points, features from cnerf_gather_features, the MLP
-    re-evaluated and differentiated by torch (rocBLAS GEMMs), feature gradients scattered by cnerf_scatter_features."""
+def _pfilm_backward(net, o, cfg, levels, cam2world, rng, saved, gc, gf):
+    """Field gradients of the per-point FiLM family (TALLSIREN, siren.py:232-331).  Per pass and chunk of images
+    cnerf_field_backward re-runs the forward storing its rows, runs the gradient chain of the eight FiLM layers on the MFMA
+    units and leaves g_pre_l = d/d(W_l y_{l-1} + b_l) and G = d/d(output of the mapping network's second Linear) in the
+    chunk buffers (include/cnerf.h); what remains are reductions over those matrices: cnerf_weight_grad for the (H,H) layer
+    matrices, library GEMMs for the (2LH, 256) mapping Linear and the two thin ones, cnerf_scatter_features for the volume."""
     fvol = levels[0]
-    B = fvol.shape[0]
-    H = int(net.hidden_dim)
-    ps = [p.detach().requires_grad_(True) for p in net.field_params()]
+    B, R, S, hier = o["B"], o["R"], o["S"], o["hier"]
+    dev = fvol.device
+    H, nl = int(net.hidden_dim), len(net.spec.layers)
+    npi = R * R * S
+    vs = volumes_struct(levels)
+    packed = pack_field(net, cfg)
+    packed_t = pack_field_transposed(net, cfg)
+    ps = [_f32(p.detach()) for p in net.field_params()]       # Wm1, bm1, Wm2, bm2, (W_l, b_l) x L, W_head, b_head
     grads = [torch.zeros_like(p) for p in ps]
     g_level = torch.zeros_like(fvol)
-    c_pts, f_pts = saved[4], saved[5]
-    cfg1 = make_cfg(net, 1, int(fvol.shape[1]))
-    for pts_all, g_all in [(c_pts, gc)] + ([(f_pts, gf)] if hier else []):
-        pts_all = pts_all.reshape(B, -1, 3)
-        g_all = g_all.reshape(B, -1, 4)
-        n = pts_all.shape[1]
-        for b in range(B):
-            for s0 in range(0, n, PFILM_CHUNK_POINTS):
-                pts = pts_all[b, s0:s0 + PFILM_CHUNK_POINTS].contiguous()
-                feat = gather_features(net, fvol[b:b + 1], pts.unsqueeze(0))[0].requires_grad_(True)
-                with torch.enable_grad():
-                    out = _pfilm_mlp(net.spec, ps, feat, pts, H)
-                gs = torch.autograd.grad(out, ps + [feat], g_all[b, s0:s0 + PFILM_CHUNK_POINTS])
-                for acc, g in zip(grads, gs[:-1]):
-                    acc += g
-                d_feat = gs[-1].contiguous()
-                L.check(L.lib().cnerf_scatter_features(C.byref(cfg1), L.ptr(pts), pts.shape[0], L.ptr(d_feat),
-                                                       L.ptr(g_level[b:b + 1]), _stream()), "cnerf_scatter_features")
+    gvs = volumes_struct([g_level])
+    c_rs, c_z, f_rs, f_z, c_pts, f_pts = saved[:6]
+    per_image = npi * (32 + 256 + 7 * nl * H + 4) * 4
+    nb = max(1, min(B, ACT_BUDGET_BYTES // per_image))
+    u_strat = _f32(rng.get("u_strat"))
+    act = None
+    passes = [(0, gc, c_rs, c_pts)] + ([(1, gf, f_rs, f_pts)] if hier else [])
+    for pss, g_out, saved_out, pts_all in passes:
+        pts_all = pts_all.reshape(B, npi, 3)
+        for b0 in range(0, B, nb):
+            cnt = min(nb, B - b0)
+            n = cnt * npi
+            if act is None or act[0].shape[0] != n:
+                act = None          # release the previous chunk before allocating a differently sized one
+                act = (torch.empty((n, 32), dtype=torch.float32, device=dev),
+                       torch.empty(nl * n * H + n * 256, dtype=torch.float32, device=dev),
+                       torch.empty((3 * nl, n, H), dtype=torch.float32, device=dev),
+                       torch.empty(3 * nl * n * H, dtype=torch.float32, device=dev),
+                       torch.empty((n, 4), dtype=torch.float32, device=dev))
+            a_feat, a_h, a_c, a_g, a_go = act
+            L.check(L.lib().cnerf_field_backward(C.byref(cfg), pss, b0, cnt, C.byref(vs), L.ptr(packed), L.ptr(packed_t), None, None,
+                                                 L.ptr(cam2world), L.ptr(u_strat), L.ptr(f_z) if hier else None, L.ptr(g_out),
+                                                 L.ptr(saved_out), L.ptr(a_feat), L.ptr(a_h), L.ptr(a_c), L.ptr(a_g), L.ptr(a_go),
+                                                 C.byref(gvs), _stream()), "cnerf_field_backward")
+            y, m = a_h[:nl * n * H].view(nl, n, H), a_h[nl * n * H:].view(n, 256)
+            gp, G = a_g[:nl * n * H].view(nl, n, H), a_g[nl * n * H:].view(n, 2 * nl * H)
+            pts = pts_all[b0:b0 + cnt].reshape(n, 3)
+            if DEBUG_CAPTURE is not None:
+                DEBUG_CAPTURE.setdefault(("pfilm", pss), dict(feat=a_feat.clone(), y=y.clone(), m=m.clone(), c=a_c.clone(), gp=gp.clone(),
+                                                              G=G.clone(), go=a_go.clone(), pts=pts.clone()))
+            grads[4] += gp[0].t() @ pts                                   # layer 0 reads the sample position: (H, 3)
+            grads[5] += gp[0].sum(0)
+            for l in range(1, nl):
+                dWl = torch.zeros((cnt, H, H), dtype=torch.float32, device=dev)
+                cs = torch.zeros((cnt, H), dtype=torch.float32, device=dev)
+                L.check(L.lib().cnerf_weight_grad(cnt, npi, H, H, L.ptr(gp[l]), L.ptr(y[l - 1]), L.ptr(dWl), L.ptr(cs), _stream()),
+                        "cnerf_weight_grad")
+                grads[4 + 2 * l] += dWl.sum(0)
+                grads[5 + 2 * l] += cs.sum(0)
+            grads[4 + 2 * nl] += a_go.t() @ y[nl - 1]
+            grads[5 + 2 * nl] += a_go.sum(0)
+            # mapping network: Linear(C, 256) -> LeakyReLU(0.2) -> Linear(256, 2 L H)
+            grads[2] += G.t() @ m
+            grads[3] += G.sum(0)
+            g_m = G @ ps[2]
+            g_m *= torch.where(m > 0, 1.0, 0.2)
+            grads[0] += g_m.t() @ a_feat
+            grads[1] += g_m.sum(0)
+            d_feat = (g_m @ ps[0]).contiguous()
+            cfgc = make_cfg(net, cnt, int(fvol.shape[1]))
+            L.check(L.lib().cnerf_scatter_features(C.byref(cfgc), L.ptr(pts), npi, L.ptr(d_feat), L.ptr(g_level[b0:b0 + cnt]), _stream()),
+                    "cnerf_scatter_features")
     return [g_level], None, None, grads
 
 
@@ -575,7 +596,7 @@ def render_backward(net, o, levels, freq, phase, cam2world, rng, saved, grad_pix
                                                        L.ptr(f_z) if hier else None, L.ptr(eps_final), L.ptr(_f32(grad_pixels)),
                                                        L.ptr(gd), L.ptr(gc), L.ptr(gf) if hier else None, _stream()),
                 "cnerf_merge_composite_backward")
-        return _pfilm_backward(net, cfg, levels, saved, gc, gf, hier)
+        return _pfilm_backward(net, o, cfg, levels, cam2world, rng, saved, gc, gf)
     vs = volumes_struct(levels)
     packed = pack_field(net, cfg)
     packed_t = pack_field_transposed(net, cfg32)

@@ -232,7 +232,19 @@ int cnerf_render_forward(const cnerf_cfg* cfg, const cnerf_volumes* vols, const 
  *             dphase_l = colsum(act_g[l]);   dfreq_l = rowsum(W_l * dWarg_l) + b_l * dphase_l   (per image)
  *             dW_head = act_go^T x_L;        db_head = colsum(act_go)
  * A residual block owns two consecutive slabs of act_h / act_c / act_g (fc1 then fc2); L in the shapes above then counts
- * slabs:  dW_fc1 = act_g[s]^T x_in, dW_fc2 = act_g[s+1]^T act_h[s]. */
+ * slabs:  dW_fc1 = act_g[s]^T x_in, dW_fc2 = act_g[s+1]^T act_h[s].
+ *
+ * Per-point FiLM family (CNERF_LAYER_PFILM, TALLSIREN siren.py:232-331:  m = LeakyReLU_0.2(Wm1 feat + bm1), [f | p] = Wm2 m + bm2,
+ * y_l = sin((15 f_l + 30) (W_l y_{l-1} + b_l) + p_l), y_-1 = xyz): the same call with larger chunk buffers --
+ *             act_feat (n,32)                  looked-up feature            act_go (n,4)  d/d head pre-activation
+ *             act_h  L (n,H) slabs of y_l, then m (n,256)                    (L*n*H + n*256 floats)
+ *             act_c  3L (n,H) slabs: per layer cos(arg), cos*freq, cos*15*pre   (private to the call)
+ *             act_g  L (n,H) slabs of g_pre_l = d/d (W_l y_{l-1} + b_l), then G (n, 2*L*H) = d/d (Wm2 m + bm2), row by row in
+ *                    that Linear's output order [f of layers 0..L-1 | p of layers 0..L-1]           (3*L*n*H floats)
+ *         and no volume scatter (grad_vols is not touched).  The caller finishes with plain GEMMs:
+ *             dW_l = act_g[l]^T y_{l-1} (cnerf_weight_grad; layer 0: y_-1 = the sample positions), db_l = colsum(act_g[l]),
+ *             dWm2 = G^T m, dbm2 = colsum(G), g_m = (G Wm2) * (m > 0 ? 1 : 0.2), dWm1 = g_m^T feat, dbm1 = colsum(g_m),
+ *             d feat = g_m Wm1 -> cnerf_scatter_features. */
 
 /* packed_t: transposed packed weights for the backward; bytes via cnerf_backward_bytes. */
 int cnerf_backward_bytes(const cnerf_cfg* cfg, size_t* packed_t);

@@ -6,13 +6,14 @@ import torch, cnerf_amd
 from cnerf_amd.generators import ImplicitGenerator3d
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 dev = torch.device("cuda:0"); torch.manual_seed(0)
-gen = ImplicitGenerator3d("SHORTSIREN_FG", 256, 32, 4, 256).to(dev); gen.set_device(dev)
+VARIANT = os.environ.get("CNERF_VARIANT", "SHORTSIREN_FG")      # TALLSIREN: z = the bare feature volume, input = xyz
+gen = (ImplicitGenerator3d("TALLSIREN", 32, 3, 4, 256) if VARIANT == "TALLSIREN" else ImplicitGenerator3d(VARIANT, 256, 32, 4, 256)).to(dev); gen.set_device(dev)
 gen.siren.precision = sys.argv[2] if len(sys.argv) > 2 else "fp32"
 gen.siren.backward_precision = sys.argv[3] if len(sys.argv) > 3 else "fp32"
 fvol = torch.randn(B, 32, 64, 64, 64, device=dev, requires_grad=True); glob = torch.randn(B, 256, device=dev, requires_grad=True)
 cam = torch.eye(4, device=dev).unsqueeze(0).repeat(B, 1, 1); cam[:, 2, 3] = -1.0
 def step(bwd):
-    px, dp = gen((fvol, glob), cam, 128, 49.134342641202636, 0.25, 1.95, 64, True, clamp_mode="relu", nerf_noise=1.0, white_back=True)
+    px, dp = gen((fvol, glob) if gen.siren.spec.has_global else fvol, cam, 128, 49.134342641202636, 0.25, 1.95, 64, True, clamp_mode="relu", nerf_noise=1.0, white_back=True)
     if bwd:
         (px.square().mean() + dp.mean()).backward()
 for bwd in (False, True):
@@ -22,4 +23,4 @@ for bwd in (False, True):
     for _ in range(n): step(bwd)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
     print(f"{gen.siren.precision} bwd {gen.siren.backward_precision} B={B} {'fwd+bwd' if bwd else 'fwd    '}: {dt*1e3:8.1f} ms/step  {B*128*128/dt/1e6:.3f} M rays/s  peak mem {torch.cuda.max_memory_allocated()/2**30:.1f} GiB", flush=True)
-print("grad norms", fvol.grad.norm().item(), glob.grad.norm().item(), gen.siren.network[0].layer.weight.grad.norm().item())
+print("grad norms", fvol.grad.norm().item(), glob.grad.norm().item() if glob.grad is not None else None, gen.siren.network[0].layer.weight.grad.norm().item())

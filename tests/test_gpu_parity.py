@@ -981,6 +981,17 @@ def test_backward_ragged_shapes_vs_oracle_autograd(dev, shape, backward_precisio
     """Gradients at point counts that are NOT a multiple of the 32-point tile (175, 297, 144 points per image: padded last
     tiles, idle waves in the last tile group, several images) against autograd through the CPU oracle, fine depths forced:
     every parameter, the FiLM mapping, the feature volume and the global feature."""
+    _ragged_backward_case(dev, shape, "SHORTSIREN_FG", backward_precision)
+
+
+@pytest.mark.parametrize("shape", [dict(B=2, R=5, S=7, V=9, H=64), dict(B=1, R=3, S=33, V=6, H=128), dict(B=3, R=4, S=9, V=5, H=256)])
+def test_backward_per_point_film_vs_oracle_autograd(dev, shape):
+    """The same for TALLSIREN (per-point FiLM, siren.py:232-331): storing forward + gradient chain kernels, weight-gradient
+    reductions and the mapping network's GEMMs against autograd through the CPU oracle, at all three widths and ragged tiles."""
+    _ragged_backward_case(dev, shape, "TALLSIREN", "fp32")
+
+
+def _ragged_backward_case(dev, shape, variant, backward_precision):
     import cnerf_amd
     from cnerf_amd.generators import ImplicitGenerator3d
     from cnerf_amd.generators.volumetric_rendering import sample_camera_positions, create_cam2world_matrix
@@ -989,26 +1000,28 @@ def test_backward_ragged_shapes_vs_oracle_autograd(dev, shape, backward_precisio
     torch.manual_seed(B * 100 + S)
     np.random.seed(B * 100 + S)
     Z = 32
-    gen = ImplicitGenerator3d("SHORTSIREN_FG", Z, 32, 4, H)
+    has_glob = variant != "TALLSIREN"
+    gen = ImplicitGenerator3d(variant, Z, 32, 4, H) if has_glob else ImplicitGenerator3d(variant, 32, 3, 4, H)
     with torch.no_grad():
         gen.siren.final_layer.weight[3] *= 20
-    fvol, glob = torch.randn(B, 32, V, V, V) * 0.5, torch.randn(B, Z)
+    fvol, glob = torch.randn(B, 32, V, V, V) * 0.5, (torch.randn(B, Z) if has_glob else None)
     cam = create_cam2world_matrix(sample_camera_positions("cpu", "y", 0.7, 1.5, B), "y")
     P = R * R
     rng = {"u_strat": torch.rand(B, P, S), "eps_coarse": torch.randn(B, P, S), "u_fine": torch.rand(B, P, S), "eps_final": torch.randn(B, P, 2 * S)}
     def oracle_grads(dtype):
         c = lambda t: t.detach().clone().to(dtype)
         params = {k: c(v).requires_grad_(True) for k, v in gen.siren.state_dict().items()}
-        fv_r, gl_r = c(fvol).requires_grad_(True), c(glob).requires_grad_(True)
+        fv_r, gl_r = c(fvol).requires_grad_(True), (c(glob).requires_grad_(True) if has_glob else None)
         torch.set_default_dtype(dtype)
         try:
-            ref = O.render("SHORTSIREN_FG", params, fv_r, gl_r, c(cam), R, 49.13, 0.25, 1.95, S, True, "softplus", 0.3, True, False,
+            ref = O.render(variant, params, fv_r, gl_r, c(cam), R, 49.13, 0.25, 1.95, S, True, "softplus", 0.3, True, False,
                            c(rng["u_strat"]), c(rng["eps_coarse"]), c(rng["u_fine"]), c(rng["eps_final"]),
                            forced_fine_z=None if dtype == torch.float32 else forced)
         finally:
             torch.set_default_dtype(torch.float32)
-        grads = torch.autograd.grad(ref.pixels.square().mean() + ref.depth.mean(), [fv_r, gl_r] + list(params.values()))
-        names = ["feature_volume", "global_feature"] + list(params.keys())
+        leaves = [fv_r] + ([gl_r] if has_glob else []) + list(params.values())
+        grads = torch.autograd.grad(ref.pixels.square().mean() + ref.depth.mean(), leaves)
+        names = ["feature_volume"] + (["global_feature"] if has_glob else []) + list(params.keys())
         return ref, {k: v.float().numpy() for k, v in zip(names, grads)}
 
     forced = None
@@ -1022,10 +1035,13 @@ def test_backward_ragged_shapes_vs_oracle_autograd(dev, shape, backward_precisio
     gen.siren.backward_precision = backward_precision
     r = {k: v.to(dev) for k, v in rng.items()}
     r["fine_z"] = ref.aux["fine_z"].detach().to(dev)
-    fv, gl = fvol.to(dev).requires_grad_(True), glob.to(dev).requires_grad_(True)
-    px, dp = gen((fv, gl), cam.to(dev), R, 49.13, 0.25, 1.95, S, True, clamp_mode="softplus", nerf_noise=0.3, white_back=True, _rng=r)
+    fv, gl = fvol.to(dev).requires_grad_(True), (glob.to(dev).requires_grad_(True) if has_glob else None)
+    px, dp = gen((fv, gl) if has_glob else fv, cam.to(dev), R, 49.13, 0.25, 1.95, S, True, clamp_mode="softplus", nerf_noise=0.3,
+                 white_back=True, _rng=r)
     (px.square().mean() + dp.mean()).backward()
-    got = {"feature_volume": fv.grad, "global_feature": gl.grad}
+    got = {"feature_volume": fv.grad}
+    if has_glob:
+        got["global_feature"] = gl.grad
     got.update({k: p.grad for k, p in gen.siren.named_parameters()})
     for k, w in want.items():
         floor = scaled_err(w, exact[k])
