@@ -8,7 +8,7 @@ LIB_PATH = os.path.join(HERE, "libcnerf_hip.so")
 
 MAX_LAYERS = 16
 MAX_LEVELS = 4
-ABI_VERSION = 4
+ABI_VERSION = 5
 F_HIERARCHICAL, F_WHITE_BACK, F_LAST_BACK, F_SOFTPLUS, F_SIGMOID_RGB, F_INPUT_XYZ = 1, 2, 4, 8, 16, 32
 PREC_FP32, PREC_FP16, PREC_FP16X3 = 0, 1, 2
 PREC_CODE = {"fp32": PREC_FP32, "fp16": PREC_FP16, "fp16x3": PREC_FP16X3}
@@ -22,7 +22,8 @@ class Cfg(C.Structure):
                 ("ray_start", C.c_float), ("ray_end", C.c_float), ("voxel_length", C.c_float),
                 ("noise_std", C.c_float), ("flags", C.c_uint32), ("fov_deg", C.c_double),
                 ("n_levels", C.c_int32), ("level_V", C.c_int32 * MAX_LEVELS), ("level_C", C.c_int32 * MAX_LEVELS),
-                ("precision", C.c_int32), ("philox", C.c_uint32), ("philox_offset", C.c_uint32), ("philox_seed", C.c_uint64)]
+                ("precision", C.c_int32), ("philox", C.c_uint32), ("philox_offset", C.c_uint32), ("philox_seed", C.c_uint64),
+                ("drop_p", C.c_float), ("reserved0", C.c_uint32)]
 
 
 class Volumes(C.Structure):
@@ -37,7 +38,7 @@ class FieldParams(C.Structure):
 
 class Rng(C.Structure):
     _fields_ = [("u_strat", C.c_void_p), ("eps_coarse", C.c_void_p), ("u_fine", C.c_void_p), ("eps_final", C.c_void_p),
-                ("fine_z", C.c_void_p)]
+                ("fine_z", C.c_void_p), ("drop_coarse", C.c_void_p), ("drop_fine", C.c_void_p)]
 
 
 AUX_FIELDS = ("coarse_points", "coarse_z", "coarse_rgb_sigma", "coarse_weights", "cdf", "inds", "fine_z",
@@ -77,7 +78,7 @@ PROTOTYPES = {
     "cnerf_pack_field_transposed": (C.c_int, [C.POINTER(Cfg), C.POINTER(FieldParams), C.c_void_p, C.c_void_p]),
     "cnerf_merge_composite_backward": (C.c_int, [C.POINTER(Cfg)] + [C.c_void_p] * 10),
     "cnerf_field_backward": (C.c_int, [C.POINTER(Cfg), C.c_int32, C.c_int32, C.c_int32, C.POINTER(Volumes)] + [C.c_void_p] * 14 +
-                             [C.POINTER(Volumes), C.c_void_p]),
+                             [C.POINTER(Volumes), C.c_void_p, C.c_void_p]),
     "cnerf_weight_grad16": (C.c_int, [C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 6),
     "cnerf_backward16_bytes": (C.c_int, [C.POINTER(Cfg), C.POINTER(C.c_size_t)]),
     "cnerf_pack_field_chain16": (C.c_int, [C.POINTER(Cfg), C.POINTER(FieldParams), C.c_void_p, C.c_void_p]),

@@ -59,6 +59,8 @@ int check_cfg(const cnerf_cfg* c, bool need_render) {
         for (int l = 0; l < c->L; ++l)
             if (c->layer_kind[l] == CNERF_LAYER_PFILM)
                 return fail(CNERF_EINVAL, "precisions fp16x3 / fp16 do not cover the per-point FiLM family");
+    if (!(c->drop_p >= 0.0f && c->drop_p < 1.0f)) return fail(CNERF_EINVAL, "drop_p=%g out of [0,1)", (double)c->drop_p);
+    if (c->drop_p > 0.0f && c->precision != CNERF_PREC_FP32) return fail(CNERF_EINVAL, "dropout (drop_p > 0) is implemented for precision fp32 only");
     if (need_render) {
         if (c->R < 1 || c->R > 4096) return fail(CNERF_EINVAL, "R=%d out of range [1,4096]", c->R);
         if (c->S < 2 || c->S > 128) return fail(CNERF_EINVAL, "S=%d out of range [2,128]", c->S);
@@ -194,7 +196,22 @@ int fill_field_args(FieldArgs& a, const cnerf_cfg* c, const cnerf_volumes* vols,
     for (int l = 0; l < c->L; ++l) a.layer_kind[l] = c->layer_kind[l];
     a.philox = philox_of(c);
     a.image0 = image0;
+    if (c->drop_p > 0.0f) {
+        // ATen: noise.bernoulli_(1 - p).div_(1 - p): the factor is 1 / float(1 - p) in fp32
+        a.drop_scale = 1.0f / (float)(1.0 - (double)c->drop_p);
+        const double th = (double)c->drop_p * 4294967296.0 + 0.5;
+        a.drop_thresh = th >= 4294967295.0 ? 0xffffffffu : (uint32_t)th;
+        a.n_drop = 0;
+        for (int l = 0; l < c->L; ++l) a.n_drop += c->layer_kind[l] != CNERF_LAYER_RES;
+    }
     return CNERF_OK;
+}
+
+// which keep decisions a pass uses: the injected bytes, or Philox stream `stream_id` (fill_field_args set the rest)
+void set_dropout(FieldArgs& a, const cnerf_cfg* c, const uint8_t* mask, uint32_t stream_id, long long n_per_image) {
+    a.drop_mask = c->drop_p > 0.0f ? mask : nullptr;
+    a.drop_stream = stream_id;
+    a.drop_points = (long long)c->B * n_per_image;
 }
 
 hipError_t launch_forward(const FieldArgs& a, const cnerf_cfg* c, hipStream_t stream) {
@@ -404,6 +421,7 @@ int cnerf_field_forward(const cnerf_cfg* cfg, const cnerf_volumes* vols, const f
     a.points = points;
     a.rgb_sigma = rgb_sigma;
     set_points(a, cfg->B, n_per_image);
+    set_dropout(a, cfg, nullptr, PHILOX_DROP_POINTS, n_per_image);
     if (hipError_t e = launch_forward(a, cfg, (hipStream_t)stream)) return hip_fail(e, "field kernel");
     return CNERF_OK;
 }
@@ -435,7 +453,7 @@ int cnerf_render_forward(const cnerf_cfg* cfg, const cnerf_volumes* vols, const 
     const PackedLayout pl = packed_layout(cfg);
     if (pl.n_film && (!freq || !phase)) return fail(CNERF_EINVAL, "render_forward: FiLM layers need freq and phase");
     const bool hier = cfg->flags & CNERF_F_HIERARCHICAL;
-    static const cnerf_rng no_rng = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    static const cnerf_rng no_rng = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     if (!rng) rng = &no_rng;
     if (hier && !rng->u_fine && !cfg->philox) return fail(CNERF_EINVAL, "render_forward: hierarchical sampling needs rng.u_fine (or cfg.philox)");
     hipStream_t stream = (hipStream_t)stream_;
@@ -486,6 +504,7 @@ int cnerf_render_forward(const cnerf_cfg* cfg, const cnerf_volumes* vols, const 
         fa.act_tb16 = keep ? 1 : 0;
     };
     keep_pass(0);
+    set_dropout(fa, cfg, rng->drop_coarse, PHILOX_DROP_COARSE, npi);
     mark(0);
     if (hipError_t e = launch_forward(fa, cfg, stream)) return hip_fail(e, "field kernel (coarse)");
     mark(1);
@@ -505,6 +524,7 @@ int cnerf_render_forward(const cnerf_cfg* cfg, const cnerf_volumes* vols, const 
         fa.z_out = nullptr;
         fa.points_out = aux ? aux->fine_points : nullptr;
         keep_pass(1);
+        set_dropout(fa, cfg, rng->drop_fine, PHILOX_DROP_FINE, npi);
         mark(2);
         if (hipError_t e = launch_forward(fa, cfg, stream)) return hip_fail(e, "field kernel (fine)");
         mark(3);
@@ -577,7 +597,8 @@ int cnerf_field_backward(const cnerf_cfg* cfg, int32_t pass, int32_t image0, int
                          const float* packed, const float* packed_t, const float* freq, const float* phase,
                          const float* cam2world, const float* u_strat, const float* fine_z,
                          const float* grad_rgb_sigma, const float* saved_rgb_sigma, float* act_feat, float* act_h,
-                         float* act_c, float* act_g, float* act_go, const cnerf_grad_volumes* grad_vols, void* stream_) {
+                         float* act_c, float* act_g, float* act_go, const cnerf_grad_volumes* grad_vols, const uint8_t* drop_mask,
+                         void* stream_) {
     g_err[0] = 0;
     if (int rc = check_cfg(cfg, true)) return rc;
     if (image0 < 0 || n_images < 1 || image0 + n_images > cfg->B) return fail(CNERF_EINVAL, "field_backward: image range out of [0,B)");
@@ -614,6 +635,7 @@ int cnerf_field_backward(const cnerf_cfg* cfg, int32_t pass, int32_t image0, int
     fa.act_feat = act_feat;
     fa.act_h = act_h;
     fa.act_c = act_c;
+    set_dropout(fa, cfg, drop_mask, pass == 0 ? PHILOX_DROP_COARSE : pass == 1 ? PHILOX_DROP_FINE : PHILOX_DROP_POINTS, npi);
     // the activation-storing forward runs in cfg->precision (`packed` is in that precision's layout); the gradient chain
     // below is fp32 on the transposed fp32 weights either way
     if (hipError_t e = launch_forward(fa, cfg, stream)) return hip_fail(e, "field kernel (activation store)");

@@ -200,7 +200,7 @@ __device__ __forceinline__ float philox_normal(const PhiloxKey& k, uint32_t stre
     const float u2 = (float)(o[1] >> 8) * 5.9604644775390625e-08f;            // [0, 1)
     return sqrtf(-2.0f * logf(u1)) * cosf(6.2831853071795864f * u2);
 }
-enum { PHILOX_U_STRAT = 0, PHILOX_EPS_COARSE = 1, PHILOX_U_FINE = 2, PHILOX_EPS_FINAL = 3 };
+enum { PHILOX_U_STRAT = 0, PHILOX_EPS_COARSE = 1, PHILOX_U_FINE = 2, PHILOX_EPS_FINAL = 3, PHILOX_DROP_COARSE = 4, PHILOX_DROP_FINE = 5, PHILOX_DROP_POINTS = 6 };
 
 // ---------------------------------------------------------------------------------------------------------------
 // rays and sample points (volumetric_rendering.py:73-199, generators.py:138-142)

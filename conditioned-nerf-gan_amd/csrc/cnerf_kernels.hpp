@@ -59,6 +59,13 @@ struct FieldArgs {
     int layer_kind[CNERF_MAX_LAYERS];
     PhiloxKey philox;        // in-kernel draw of u_strat where the tensor is null (cnerf_cfg.philox_*)
     int image0;              // first image of this launch inside the call (global element indices of the draws)
+    // dropout behind the sine of the FiLM / sine / per-point FiLM layers (training mode, cnerf_cfg.drop_p); drop_scale 0 = off
+    float drop_scale;        // 1 / (1 - p)
+    uint32_t drop_thresh;    // Philox word >= thresh keeps (thresh = round(p * 2^32))
+    uint32_t drop_stream;    // Philox stream of this pass (PHILOX_DROP_*)
+    int n_drop;              // dropout layers of the network (= layers that are not residual blocks)
+    long long drop_points;   // points of the whole call (B * n_per_image): row count of one layer of drop_mask
+    const uint8_t* drop_mask;  // injected keep decisions (n_drop, drop_points, H), 1 = keep; null: Philox
 };
 
 hipError_t launch_fill(float* dst, float value, int n, hipStream_t stream);

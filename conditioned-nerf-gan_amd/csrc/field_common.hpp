@@ -202,6 +202,62 @@ __device__ __forceinline__ void tile_point(const FieldArgs& a, int b, long long 
     tile_point_finish(a, b, nn, raw, valid, h, write, px, py, pz);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Dropout (nn.Dropout behind the sine, siren.py:158-159,175-176,197-198; training mode only): the factors 0 or 1/(1-p) of
+// the 4 consecutive channels c0..c0+3 of dropout layer d at point `gp` (index in the whole call).  Injected keep bytes, or
+// one Philox block per 4 channels: counter index ((gp * n_drop + d) * H + c0) / 4, word e decides channel c0 + e.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ f32x4 drop_factors(const FieldArgs& a, unsigned long long gp, int d, int H, int c0) {
+    f32x4 f;
+    if (a.drop_mask) {
+        const uint32_t m = *reinterpret_cast<const uint32_t*>(a.drop_mask + ((size_t)d * a.drop_points + gp) * H + c0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) f[e] = ((m >> (8 * e)) & 0xffu) ? a.drop_scale : 0.0f;
+    } else {
+        const unsigned long long idx = ((gp * (unsigned long long)a.n_drop + d) * H + c0) >> 2;
+        // the ten rounds as a rolled loop: this sits inside fully unrolled matrix loops, 64 times per layer
+        uint32_t c0 = (uint32_t)idx, c1 = (uint32_t)(idx >> 32), c2 = a.drop_stream, c3 = a.philox.offset;
+        uint32_t k0 = a.philox.seed_lo, k1 = a.philox.seed_hi;
+#pragma nounroll
+        for (int r = 0; r < 10; ++r) {
+            const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+            const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+            const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+            c0 = n0;
+            c1 = lo1;
+            c2 = n2;
+            c3 = lo0;
+            k0 += 0x9E3779B9u;
+            k1 += 0xBB67AE85u;
+        }
+        f[0] = c0 >= a.drop_thresh ? a.drop_scale : 0.0f;
+        f[1] = c1 >= a.drop_thresh ? a.drop_scale : 0.0f;
+        f[2] = c2 >= a.drop_thresh ? a.drop_scale : 0.0f;
+        f[3] = c3 >= a.drop_thresh ? a.drop_scale : 0.0f;
+    }
+    return f;
+}
+// ... applied to one activation tile (and, in the storing forward, to the rows of derivatives that travel with it)
+__device__ __forceinline__ void drop_tile(const FieldArgs& a, unsigned long long gp, int d, int H, int t, int h, f32x16& v) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 f = drop_factors(a, gp, d, H, 32 * t + 8 * g + 4 * h);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[4 * g + e] *= f[e];
+    }
+}
+__device__ __forceinline__ void drop_tile2(const FieldArgs& a, unsigned long long gp, int d, int H, int t, int h, f32x16& v, f32x16& w) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 f = drop_factors(a, gp, d, H, 32 * t + 8 * g + 4 * h);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[4 * g + e] *= f[e];
+            w[4 * g + e] *= f[e];
+        }
+    }
+}
+
 // XCD-aware tile ownership: blocks b and b+8 share an XCD (round-robin dispatch), so give each of the 8 block classes
 // one contiguous eighth of the tiles (a band of neighbouring rays -> a compact slab of the feature grid in that XCD's
 // L2).  Placement only changes speed, never results.

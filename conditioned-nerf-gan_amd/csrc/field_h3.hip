@@ -603,7 +603,8 @@ __global__ __launch_bounds__(256) void field_h3_kernel(FieldArgs a) {
             constexpr bool RESID = decltype(resid_tag)::value;
             const float inv_s = lds_inv_s[m];
             f32x16 acc_prev;
-            FilmPair fp, fp_done;
+            FilmPair fp;
+            [[maybe_unused]] FilmPair fp_done;            // (CNERF_H3_BALANCE only)
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const f16x8* unit = unit_begin(!PAIRED || (t & 1));   // PAIRED: unit 1 + (m-1) NT + t of the tile, even iff t is odd

@@ -120,11 +120,13 @@ __device__ __forceinline__ void store_tile_rows(float* __restrict__ row /* &buf[
 // scripts/ubench/mfma_valu_overlap.hip): VALU instructions do NOT hide under v_mfma_f32_32x32x2_f32 -- each adds its
 // full 2 cycles whether spread between the MFMAs or clumped, with one or two accumulator chains -- so for the fp32
 // path  time = MFMA + VALU + stalls  and the epilogue placement only matters for register pressure and load distance.
-template <int OT, int KT, int EPI, bool STORE>
+// DROP: the finished tile (and its cosine row) is multiplied by the dropout factors of layer `drop_d` at point `drop_gp`.
+template <int OT, int KT, int EPI, bool STORE, bool DROP = false>
 __device__ __forceinline__ void mlp_matrix(const f32x4* __restrict__ wp, const float* __restrict__ bias,
                                            const float* __restrict__ freq, const float* __restrict__ phase,
                                            const f32x16* in, const f32x16* res, f32x16* out, int lane, int h,
-                                           float* __restrict__ row_h, float* __restrict__ row_c) {
+                                           float* __restrict__ row_h, float* __restrict__ row_c,
+                                           const FieldArgs* da = nullptr, unsigned long long drop_gp = 0, int drop_d = 0) {
     constexpr int GPT = KT * 4;                       // groups (of 4 MFMAs) per output tile
     constexpr int NG = OT * GPT;
     constexpr int EPG = GPT >= 16 ? 1 : 16 / GPT;     // epilogue elements handled per group
@@ -160,6 +162,10 @@ __device__ __forceinline__ void mlp_matrix(const f32x4* __restrict__ wp, const f
                     if (STORE) cos_t[r] = cs_;
                 }
             }
+            if (DROP && t > 0 && gi == GPT - 1) {
+                if (STORE) drop_tile2(*da, drop_gp, drop_d, OT * 32, t - 1, h, out[t - 1], cos_t);
+                else drop_tile(*da, drop_gp, drop_d, OT * 32, t - 1, h, out[t - 1]);
+            }
             if (STORE && t > 0 && gi == GPT - 1) {      // tile t-1 is complete: spill it for the backward pass
                 store_tile_rows(row_h, t - 1, h, out[t - 1]);
                 store_tile_rows(row_c, t - 1, h, cos_t);
@@ -176,6 +182,10 @@ __device__ __forceinline__ void mlp_matrix(const f32x4* __restrict__ wp, const f
         out[OT - 1][r] = epilogue_one<EPI, STORE>(acc_prev[r], EPI == EPI_FILM_RES ? res[OT - 1][r] : 0.0f, fr_prev[r], ph_prev[r],
                                                   cs_);
         if (STORE) cos_t[r] = cs_;
+    }
+    if (DROP) {
+        if (STORE) drop_tile2(*da, drop_gp, drop_d, OT * 32, OT - 1, h, out[OT - 1], cos_t);
+        else drop_tile(*da, drop_gp, drop_d, OT * 32, OT - 1, h, out[OT - 1]);
     }
     if (STORE) {
         store_tile_rows(row_h, OT - 1, h, out[OT - 1]);
@@ -206,9 +216,10 @@ __device__ __forceinline__ void layer0_accumulate(const f32x4* __restrict__ wp, 
 }
 
 // x[t] = sin(freq * y[t] + phase) for all tiles (+ activation store)
-template <int NT, bool STORE>
+template <int NT, bool STORE, bool DROP = false>
 __device__ __forceinline__ void film_all(const f32x16* y, f32x16* x, const float* __restrict__ freq,
-                                         const float* __restrict__ phase, int h, float* row_h, float* row_c) {
+                                         const float* __restrict__ phase, int h, float* row_h, float* row_c,
+                                         const FieldArgs* da = nullptr, unsigned long long drop_gp = 0) {
     f32x16 fr_n = load_chan16(freq, 0, h), ph_n = load_chan16(phase, 0, h);      // per-channel vectors one tile ahead of their use
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -227,6 +238,10 @@ __device__ __forceinline__ void film_all(const f32x16* y, f32x16* x, const float
             float c_ = 0.0f;
             o[r] = epilogue_one<EPI_FILM, STORE>(y[t][r], 0.0f, fr[r], ph[r], c_);
             if (STORE) cs[r] = c_;
+        }
+        if (DROP) {
+            if (STORE) drop_tile2(*da, drop_gp, 0, NT * 32, t, h, o, cs);
+            else drop_tile(*da, drop_gp, 0, NT * 32, t, h, o);
         }
         x[t] = o;
         if (STORE) {
@@ -265,7 +280,7 @@ __device__ __forceinline__ void film_all(const f32x16* y, f32x16* x, const float
 #define CNERF_F32_LOOKUP_DMA 0
 #endif
 
-template <int NT, bool HAS_RES, bool STORE>
+template <int NT, bool HAS_RES, bool STORE, bool DROP>
 __global__ __launch_bounds__(256) void field_tile_kernel(FieldArgs a) {
 #ifdef CNERF_STAMPS
     unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -323,6 +338,8 @@ __global__ __launch_bounds__(256) void field_tile_kernel(FieldArgs a) {
         // A plain sine layer is a FiLM layer with freq = 1, phase = 0 (1*x and +0 are exact): one code path.
         Act<NT> x, y;
         const size_t gpt = (size_t)b * a.n_per_image + nn;                 // global point row of the activation buffers
+        const unsigned long long drop_gp = (unsigned long long)(b + a.image0) * a.n_per_image + nn;   // ... of the whole call
+        int drop_d = 0;                                                    // dropout layers seen so far (layer 0 is one)
         const size_t act_layer = (size_t)a.act_points * H;                 // floats per layer in act_h / act_c
         float* row_h = STORE ? a.act_h + gpt * H : nullptr;
         float* row_c = STORE ? a.act_c + gpt * H : nullptr;
@@ -351,7 +368,7 @@ __global__ __launch_bounds__(256) void field_tile_kernel(FieldArgs a) {
         STAMP(1);   // position + lookups + layer-0 products
         {
             const bool film = a.layer_kind[0] == CNERF_LAYER_FILM;
-            film_all<NT, STORE>(y.v, x.v, film ? freq : ones, film ? phase : zeros, h, row_h, row_c);
+            film_all<NT, STORE, DROP>(y.v, x.v, film ? freq : ones, film ? phase : zeros, h, row_h, row_c, &a, drop_gp);
             if (STORE) {
                 row_h += act_layer;
                 row_c += act_layer;
@@ -369,8 +386,9 @@ __global__ __launch_bounds__(256) void field_tile_kernel(FieldArgs a) {
             const int kind = a.layer_kind[l];
             if (!HAS_RES || kind != CNERF_LAYER_RES) {
                 const bool film = kind == CNERF_LAYER_FILM;
-                mlp_matrix<NT, NT, EPI_FILM, STORE>(wp, bias, film ? freq : ones, film ? phase : zeros, x.v, nullptr, y.v, lane,
-                                                    h, row_h, row_c);
+                ++drop_d;
+                mlp_matrix<NT, NT, EPI_FILM, STORE, DROP>(wp, bias, film ? freq : ones, film ? phase : zeros, x.v, nullptr, y.v, lane,
+                                                          h, row_h, row_c, &a, drop_gp, drop_d);
                 if (STORE) {
                     row_h += act_layer;
                     row_c += act_layer;
@@ -476,12 +494,13 @@ __device__ __forceinline__ f32x16 mfma_accumulate(const f32x4* __restrict__ wp, 
     return acc;
 }
 
-template <int NT, int KT, bool STORE>
+template <int NT, int KT, bool STORE, bool DROP>
 __device__ __forceinline__ void pfilm_layer(const f32x4* __restrict__ w_main, const f32x4* __restrict__ w_freq,
                                             const f32x4* __restrict__ w_phase, const float* __restrict__ b_main,
                                             const float* __restrict__ b_freq, const float* __restrict__ b_phase,
                                             const f32x16* x, const f32x16* m, f32x16* y, int lane, int h,
-                                            float* __restrict__ row_y, float* __restrict__ row_c, size_t slab) {
+                                            float* __restrict__ row_y, float* __restrict__ row_c, size_t slab,
+                                            const FieldArgs& a, unsigned long long drop_gp, int drop_d) {
     constexpr size_t TILE4 = 4 * 64;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -501,6 +520,10 @@ __device__ __forceinline__ void pfilm_layer(const f32x4* __restrict__ w_main, co
                 cf[r] = c_ * f;
                 cp[r] = c_ * (15.0f * pre[r]);
             }
+            if (DROP) {
+                drop_tile2(a, drop_gp, drop_d, NT * 32, t, h, o, cs);
+                drop_tile2(a, drop_gp, drop_d, NT * 32, t, h, cf, cp);
+            }
             if (row_y) {                       // (padded lanes of an image's last tile shadow its last point: they do not store)
                 store_tile_rows(row_y, t, h, o);
                 store_tile_rows(row_c, t, h, cs);
@@ -510,12 +533,13 @@ __device__ __forceinline__ void pfilm_layer(const f32x4* __restrict__ w_main, co
         } else {
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[r] = sin_pi_reduced((fr[r] * 15.0f + 30.0f) * pre[r] + ph[r]);
+            if (DROP) drop_tile(a, drop_gp, drop_d, NT * 32, t, h, o);
         }
         y[t] = o;
     }
 }
 
-template <int NT, bool STORE>
+template <int NT, bool STORE, bool DROP>
 __global__ __launch_bounds__(256) void field_pw_kernel(FieldArgs a) {
     const int lane = threadIdx.x & 63;
     const int j = lane & 31, h = lane >> 5;
@@ -532,6 +556,7 @@ __global__ __launch_bounds__(256) void field_pw_kernel(FieldArgs a) {
         // activation store (STORE): act_h = L slabs (n,H) of y, then m (n,256); act_c = 3L slabs (n,H): cos, cos*freq, cos*15*pre
         const size_t gpt = (size_t)b * a.n_per_image + nn;
         const size_t slab = (size_t)a.act_points * H;
+        const unsigned long long drop_gp = (unsigned long long)(b + a.image0) * a.n_per_image + nn;
         const bool st = STORE && valid;
         float* row_y = st ? a.act_h + gpt * H : nullptr;
         float* row_c = st ? a.act_c + gpt * H : nullptr;
@@ -572,13 +597,13 @@ __global__ __launch_bounds__(256) void field_pw_kernel(FieldArgs a) {
                 const f32x4* w_main = wp;
                 const f32x4* w_freq = w_main + (size_t)NT * 1 * TILE4;
                 const f32x4* w_phase = w_freq + (size_t)NT * 8 * TILE4;
-                pfilm_layer<NT, 1, STORE>(w_main, w_freq, w_phase, bias, bias + H, bias + 2 * H, &xyz, m.v, x.v, lane, h, row_y, row_c, slab);
+                pfilm_layer<NT, 1, STORE, DROP>(w_main, w_freq, w_phase, bias, bias + H, bias + 2 * H, &xyz, m.v, x.v, lane, h, row_y, row_c, slab, a, drop_gp, l);
                 wp = w_phase + (size_t)NT * 8 * TILE4;
             } else {
                 const f32x4* w_main = wp;
                 const f32x4* w_freq = w_main + (size_t)NT * NT * TILE4;
                 const f32x4* w_phase = w_freq + (size_t)NT * 8 * TILE4;
-                pfilm_layer<NT, NT, STORE>(w_main, w_freq, w_phase, bias, bias + H, bias + 2 * H, x.v, m.v, y.v, lane, h, row_y, row_c, slab);
+                pfilm_layer<NT, NT, STORE, DROP>(w_main, w_freq, w_phase, bias, bias + H, bias + 2 * H, x.v, m.v, y.v, lane, h, row_y, row_c, slab, a, drop_gp, l);
                 wp = w_phase + (size_t)NT * 8 * TILE4;
 #pragma unroll
                 for (int t = 0; t < NT; ++t) x.v[t] = y.v[t];
@@ -988,35 +1013,38 @@ hipError_t launch_field_backward(const FieldArgs& a, int H, hipStream_t stream) 
     }
 }
 
-template <int NT, bool HAS_RES, bool STORE>
+template <int NT, bool HAS_RES, bool STORE, bool DROP>
 static hipError_t launch_field_tile(const FieldArgs& a, hipStream_t stream) {
     if (a.n_in < 1 || a.in_level[0] < 0) return hipErrorInvalidValue;      // the lookup prefetch assumes a volume tile first
-    const void* fn = (const void*)field_tile_kernel<NT, HAS_RES, STORE>;
+    const void* fn = (const void*)field_tile_kernel<NT, HAS_RES, STORE, DROP>;
     const int lds_bytes = (CNERF_F32_LOOKUP_DMA && NT >= 4) ? 4 * 32 * 1024 : 0;   // lookup staging of the four waves
     // (per launch, not once per process: the attribute is per device, and a cached flag would be unsynchronised global state)
     if (lds_bytes)
         if (hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)) return e;
     const int blocks = lds_bytes ? field_grid_one_per_cu(a.total_tiles) : field_grid(fn, a.total_tiles);
-    hipLaunchKernelGGL((field_tile_kernel<NT, HAS_RES, STORE>), dim3(blocks), dim3(256), lds_bytes, stream, a);
+    hipLaunchKernelGGL((field_tile_kernel<NT, HAS_RES, STORE, DROP>), dim3(blocks), dim3(256), lds_bytes, stream, a);
     return hipGetLastError();
 }
 
 template <int NT, bool HAS_RES>
 static hipError_t launch_field_nt(const FieldArgs& a, hipStream_t stream) {
-    // a.act_h set: activation-storing forward of the backward pass
-    return a.act_h ? launch_field_tile<NT, HAS_RES, true>(a, stream) : launch_field_tile<NT, HAS_RES, false>(a, stream);
+    // a.act_h set: activation-storing forward of the backward pass; a.drop_scale != 0: dropout (training mode)
+    if (a.drop_scale != 0.0f)
+        return a.act_h ? launch_field_tile<NT, HAS_RES, true, true>(a, stream) : launch_field_tile<NT, HAS_RES, false, true>(a, stream);
+    return a.act_h ? launch_field_tile<NT, HAS_RES, true, false>(a, stream) : launch_field_tile<NT, HAS_RES, false, false>(a, stream);
 }
 
-template <int NT, bool STORE>
+template <int NT, bool STORE, bool DROP>
 static hipError_t launch_field_pw(const FieldArgs& a, hipStream_t stream) {
-    const int blocks = field_grid((const void*)field_pw_kernel<NT, STORE>, a.total_tiles);
-    hipLaunchKernelGGL((field_pw_kernel<NT, STORE>), dim3(blocks), dim3(256), 0, stream, a);
+    const int blocks = field_grid((const void*)field_pw_kernel<NT, STORE, DROP>, a.total_tiles);
+    hipLaunchKernelGGL((field_pw_kernel<NT, STORE, DROP>), dim3(blocks), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 
 template <int NT>
 static hipError_t launch_field_pw_nt(const FieldArgs& a, hipStream_t stream) {
-    return a.act_h ? launch_field_pw<NT, true>(a, stream) : launch_field_pw<NT, false>(a, stream);
+    if (a.drop_scale != 0.0f) return a.act_h ? launch_field_pw<NT, true, true>(a, stream) : launch_field_pw<NT, false, true>(a, stream);
+    return a.act_h ? launch_field_pw<NT, true, false>(a, stream) : launch_field_pw<NT, false, false>(a, stream);
 }
 
 hipError_t launch_field(const FieldArgs& a, int H, hipStream_t stream) {

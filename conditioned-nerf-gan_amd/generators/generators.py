@@ -73,6 +73,11 @@ class ImplicitGenerator3d(nn.Module):
                 self._philox_calls += 1
             else:
                 rng = draw_rng(B, R * R, S, bool(hierarchical_sample), noise_std, dev)
+        if net.drop_out and net.training and "drop" not in rng:
+            # dropout decisions are Philox draws inside the field kernels (or rng["drop_coarse"/"drop_fine"] bytes), keyed like
+            # the philox rng mode: torch's CUDA seed and one counter value per forward
+            rng = dict(rng, drop=(float(net.drop_out), rng.get("philox") or (torch.cuda.initial_seed(), net._drop_calls)))
+            net._drop_calls += 1
         aux_out = kwargs.get("_aux")
         pixels, depth, aux = ops.render(net, fvol, freq, phase, cam2worlds, R, fov, ray_start, ray_end, S,
                                         bool(hierarchical_sample), clamp_mode, noise_std, white_back, last_back, rng,

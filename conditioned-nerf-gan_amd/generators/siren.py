@@ -82,6 +82,7 @@ class FieldNetwork(nn.Module):
 
     spec: FieldSpec = None
     variant: str = None
+    _drop_calls = 0          # forwards of this module that drew dropout decisions (Philox counter offset)
 
     def __init__(self, input_dim=3, z_dim=100, hidden_dim=256, output_dim=4, drop_out=0, device=None, **kwargs):
         super().__init__()
@@ -138,14 +139,19 @@ class FieldNetwork(nn.Module):
         return out
 
     def check_supported(self):
-        if self.drop_out and self.training:
-            raise NotImplementedError("drop_out > 0 in training mode is not supported by the HIP render path")
+        """Dropout (training mode, drop_out > 0: siren.py:158-159,175-176,197-198) runs in the fp32 kernels only."""
+        if self.drop_out and self.training and (ops.precision_of(self) != "fp32" or ops.backward_precision_of(self) != "fp32"):
+            raise NotImplementedError("drop_out > 0 in training mode needs precision = backward_precision = 'fp32'")
 
     def forward(self, points, z, img_size=None, num_steps=None):
         self.check_supported()
         fvol, glob = self.split_z(z)
         freq, phase = self.film(glob)
-        return ops.field_forward(self, fvol, freq, phase, points)
+        drop = None
+        if self.drop_out and self.training:     # keep decisions: Philox under torch's CUDA seed, one counter value per call
+            drop = (float(self.drop_out), (torch.cuda.initial_seed(), self._drop_calls))
+            self._drop_calls += 1
+        return ops.field_forward(self, fvol, freq, phase, points, drop=drop)
 
 
 class PointFeaturesMappingNetwork(nn.Module):

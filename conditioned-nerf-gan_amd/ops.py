@@ -60,7 +60,7 @@ def precision_of(net):
 
 
 def make_cfg(net, B, vols, R=1, S=2, fov=30.0, ray_start=0.0, ray_end=1.0, noise_std=0.0, hierarchical=False,
-             white_back=False, last_back=False, clamp_mode="relu", precision=None, philox=None):
+             white_back=False, last_back=False, clamp_mode="relu", precision=None, philox=None, drop=None):
     """cnerf_cfg for a field network `net` (generators.siren.FieldNetwork); vols: channel-last volume(s) or, for calls
     that touch no volume, the side V of a single 32-channel one."""
     cfg = L.Cfg()
@@ -98,7 +98,20 @@ def make_cfg(net, B, vols, R=1, S=2, fov=30.0, ray_start=0.0, ray_end=1.0, noise
     cfg.precision = L.PREC_CODE[precision if precision is not None else precision_of(net)]
     if philox is not None:            # (seed, offset): draws without a tensor are generated in the kernels
         cfg.philox, cfg.philox_seed, cfg.philox_offset = 1, int(philox[0]) & 0xFFFFFFFFFFFFFFFF, int(philox[1]) & 0xFFFFFFFF
+    if drop is not None:              # (p, (seed, offset)): dropout of a network in training mode, see drop_of()
+        cfg.drop_p = float(drop[0])
+        if philox is None:            # the key of the keep decisions (the four draws stay tensors: cfg.philox = 0)
+            cfg.philox_seed, cfg.philox_offset = int(drop[1][0]) & 0xFFFFFFFFFFFFFFFF, int(drop[1][1]) & 0xFFFFFFFF
     return cfg
+
+
+def drop_of(rng):
+    """rng["drop"] = (p, (seed, offset)) when the network drops out in this call (ImplicitGenerator3d.forward sets it in training mode)."""
+    return (rng or {}).get("drop")
+
+
+def _u8(t):
+    return None if t is None else t.to(torch.uint8).contiguous()
 
 
 def sizes(cfg, render=True):
@@ -178,12 +191,12 @@ def gather_features(net, fvol_cl, points):
     return out
 
 
-def field_forward(net, fvol, freq, phase, points, fvol_is_channel_last=False):
-    """rgb_sigma (B,n,4) of `net` at explicit world points (B,n,3)."""
+def field_forward(net, fvol, freq, phase, points, fvol_is_channel_last=False, drop=None):
+    """rgb_sigma (B,n,4) of `net` at explicit world points (B,n,3).  drop = (p, (seed, offset)): dropout of a training-mode call."""
     points = _f32(points)
     B, n = points.shape[0], points.shape[1]
     levels = [_f32(v) for v in as_levels(fvol)] if fvol_is_channel_last else channel_last_levels(fvol)
-    cfg = make_cfg(net, B, levels)
+    cfg = make_cfg(net, B, levels, drop=drop)
     packed = pack_field(net, cfg)
     out = torch.empty((B, n, 4), dtype=torch.float32, device=points.device)
     vs = volumes_struct(levels)
@@ -260,7 +273,7 @@ def render_forward(net, fvol, freq, phase, cam2world, img_size, fov, ray_start, 
     dev = cam2world.device
     levels = [_f32(v) for v in as_levels(fvol)] if fvol_is_channel_last else channel_last_levels(fvol)
     cfg = make_cfg(net, B, levels, R, S, fov, ray_start, ray_end, noise_std, hierarchical, white_back,
-                   last_back, clamp_mode, philox=(rng or {}).get("philox"))
+                   last_back, clamp_mode, philox=(rng or {}).get("philox"), drop=drop_of(rng))
     vs = volumes_struct(levels)
     packed = pack_field(net, cfg)
     _, _, ws_bytes = sizes(cfg)
@@ -271,6 +284,8 @@ def render_forward(net, fvol, freq, phase, cam2world, img_size, fov, ray_start, 
     keep = [_f32(rng.get(k)) for k in ("u_strat", "eps_coarse", "u_fine", "eps_final", "fine_z")]
     r = L.Rng()
     r.u_strat, r.eps_coarse, r.u_fine, r.eps_final, r.fine_z = [None if t is None else t.data_ptr() for t in keep]
+    keep += [_u8(rng.get(k)) for k in ("drop_coarse", "drop_fine")]       # injected dropout decisions (tests)
+    r.drop_coarse, r.drop_fine = [None if t is None else t.data_ptr() for t in keep[-2:]]
     for t in keep:
         L.ptr(t)   # validates device / contiguity
     aux_t, aux_s = {}, None
@@ -364,7 +379,8 @@ def _pfilm_backward(net, o, cfg, levels, cam2world, rng, saved, gc, gf):
             L.check(L.lib().cnerf_field_backward(C.byref(cfg), pss, b0, cnt, C.byref(vs), L.ptr(packed), L.ptr(packed_t), None, None,
                                                  L.ptr(cam2world), L.ptr(u_strat), L.ptr(f_z) if hier else None, L.ptr(g_out),
                                                  L.ptr(saved_out), L.ptr(a_feat), L.ptr(a_h), L.ptr(a_c), L.ptr(a_g), L.ptr(a_go),
-                                                 C.byref(gvs), _stream()), "cnerf_field_backward")
+                                                 C.byref(gvs), L.ptr(_u8(rng.get("drop_fine" if pss else "drop_coarse"))), _stream()),
+                    "cnerf_field_backward")
             y, m = a_h[:nl * n * H].view(nl, n, H), a_h[nl * n * H:].view(n, 256)
             gp, G = a_g[:nl * n * H].view(nl, n, H), a_g[nl * n * H:].view(n, 2 * nl * H)
             pts = pts_all[b0:b0 + cnt].reshape(n, 3)
@@ -583,9 +599,9 @@ def render_backward(net, o, levels, freq, phase, cam2world, rng, saved, grad_pix
     dev = cam2world.device
     # cfg: precision of the forward (the activation-storing re-run follows it); cfg32: the fp32 gradient chain
     cfg = make_cfg(net, B, levels, R, S, o["fov"], o["ray_start"], o["ray_end"], o["noise_std"], hier,
-                   o["white_back"], o["last_back"], o["clamp_mode"], philox=rng.get("philox"))
+                   o["white_back"], o["last_back"], o["clamp_mode"], philox=rng.get("philox"), drop=drop_of(rng))
     cfg32 = make_cfg(net, B, levels, R, S, o["fov"], o["ray_start"], o["ray_end"], o["noise_std"], hier,
-                     o["white_back"], o["last_back"], o["clamp_mode"], precision="fp32", philox=rng.get("philox"))
+                     o["white_back"], o["last_back"], o["clamp_mode"], precision="fp32", philox=rng.get("philox"), drop=drop_of(rng))
     if net.spec.layers[0] == "pfilm":
         c_rs, c_z, f_rs, f_z = saved[:4]
         gc = torch.empty_like(c_rs)
@@ -655,7 +671,8 @@ def render_backward(net, o, levels, freq, phase, cam2world, rng, saved, grad_pix
                                                  L.ptr(freq), L.ptr(phase), L.ptr(cam2world), L.ptr(u_strat),
                                                  L.ptr(fine_z_used) if hier else None, L.ptr(g_out), L.ptr(saved_out),
                                                  L.ptr(a_feat), L.ptr(a_h), L.ptr(a_c), L.ptr(a_g), L.ptr(a_go),
-                                                 C.byref(gvs), _stream()), "cnerf_field_backward")
+                                                 C.byref(gvs), L.ptr(_u8(rng.get("drop_fine" if pss else "drop_coarse"))), _stream()),
+                    "cnerf_field_backward")
             if DEBUG_CAPTURE is not None:
                 DEBUG_CAPTURE.setdefault(("f32", pss), dict(feat=a_feat.clone(), h=a_h.clone(), c=a_c.clone(), g=a_g.clone(), go=a_go.clone(), cnt=cnt))
             # parameter gradients: plain GEMMs and column sums over the chunk matrices (rocBLAS through torch)

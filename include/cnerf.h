@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define CNERF_ABI_VERSION 4
+#define CNERF_ABI_VERSION 5
 
 #define CNERF_OK 0
 #define CNERF_EINVAL (-22)  /* bad argument / unsupported shape (message via cnerf_last_error) */
@@ -88,6 +88,16 @@ typedef struct cnerf_cfg {
     uint32_t philox;
     uint32_t philox_offset;
     uint64_t philox_seed;
+    /* Dropout in training mode (ABI v5): nn.Dropout(p) behind the sine of every FiLMLayer / SirenLayer / PointwiseFiLMLayer
+     * (siren.py:158-159,175-176,197-198; residual blocks have none).  drop_p in [0,1), 0 = off (eval mode).  Kept values are
+     * multiplied by 1 / (1 - p) like ATen does.  Keep decisions per (dropout layer d, point, channel): the bytes of
+     * cnerf_rng.drop_coarse / drop_fine where given, else Philox4x32-10 under (philox_seed, philox_offset) -- whether or not
+     * `philox` is set -- stream 4 (coarse pass), 5 (fine pass), 6 (cnerf_field_forward), one block per 4 channels: counter index
+     * ((point index in the whole call * n_drop + d) * H + c) / 4, word c % 4 keeps iff >= round(p * 2^32); n_drop = number of
+     * layers that are not residual blocks.  The backward entry points given the same cfg (and masks) see the same decisions.
+     * Precision fp32 only (CNERF_EINVAL otherwise). */
+    float drop_p;
+    uint32_t reserved0;
 } cnerf_cfg;
 
 /* Feature volumes, channel-last: level[i] is (B, V_i, V_i, V_i, C_i).  HOST struct of device pointers.  The gradient
@@ -124,13 +134,17 @@ typedef struct cnerf_field_params {
  * eps_final is indexed in SORTED sample order, as the reference adds its noise after the merge.
  *   fine_z     (B,P,S)   test hook, normally NULL: depths that REPLACE the resampled ones for the fine pass and the merge
  *                        (the resampling still runs and fills aux).  The field is chaotic in position, so parity of the
- *                        fine pass / merge / final composite is pinned by forcing the reference's own fine depths. */
+ *                        fine pass / merge / final composite is pinned by forcing the reference's own fine depths.
+ *   drop_coarse, drop_fine (n_drop, B, P*S, H) uint8, 1 = keep: dropout decisions of the two field passes (cnerf_cfg.drop_p;
+ *                        normally NULL: Philox).  What F.dropout drew in the reference, layer after layer, for tests. */
 typedef struct cnerf_rng {
     const float* u_strat;
     const float* eps_coarse;
     const float* u_fine;
     const float* eps_final;
     const float* fine_z;
+    const uint8_t* drop_coarse;
+    const uint8_t* drop_fine;
 } cnerf_rng;
 
 /* Optional intermediate outputs (each may be NULL).  Shapes per image-major layout:
@@ -264,12 +278,15 @@ int cnerf_merge_composite_backward(const cnerf_cfg* cfg, const float* coarse_rgb
  * full gradient volumes, accumulated into (zero them first).  act_* are chunk buffers for n_images images; act_feat is
  * (n, 32 * input tiles): the concatenated looked-up features (and xyz, zero padded) that layer 0 saw.
  * `packed` is in the layout of cfg->precision (the activation-storing forward runs in that precision); packed_t is always
- * the fp32 transposed layout (the gradient chain is fp32). */
+ * the fp32 transposed layout (the gradient chain is fp32).  drop_mask: cnerf_rng.drop_coarse / drop_fine of that pass (the FULL
+ * tensor) or NULL; with cfg->drop_p > 0 the stored sine and cosine rows carry the dropout factor, so the chain, the weight
+ * reductions and the scatter are the ones of the eval-mode network. */
 int cnerf_field_backward(const cnerf_cfg* cfg, int32_t pass, int32_t image0, int32_t n_images, const cnerf_volumes* vols,
                          const float* packed, const float* packed_t, const float* freq, const float* phase,
                          const float* cam2world, const float* u_strat, const float* fine_z,
                          const float* grad_rgb_sigma, const float* saved_rgb_sigma, float* act_feat, float* act_h,
-                         float* act_c, float* act_g, float* act_go, const cnerf_grad_volumes* grad_vols, void* stream);
+                         float* act_c, float* act_g, float* act_go, const cnerf_grad_volumes* grad_vols, const uint8_t* drop_mask,
+                         void* stream);
 
 /* Weight-gradient reduction over a chunk written by cnerf_field_backward:  dW[b] (H,K) += g_arg[b]^T x[b],
  * colsum[b] (H) += sum over points of g_arg[b], per image b < n_images; g_arg (n_images, n_per_image, H) = act_g of one

@@ -43,3 +43,14 @@ def normal(seed, offset, stream_id, n):
     u1 = ((o0 >> np.uint32(8)) + np.uint32(1)).astype(np.float32) * np.float32(2.0 ** -24)
     u2 = (o1 >> np.uint32(8)).astype(np.float32) * np.float32(2.0 ** -24)
     return (np.sqrt(np.float32(-2.0) * np.log(u1)) * np.cos(np.float32(6.2831853071795864) * u2)).astype(np.float32)
+
+
+def dropout_keep(seed, offset, stream_id, n_points, n_drop, H, p):
+    """Keep decisions (n_drop, n_points, H) uint8 of the kernels' dropout under (seed, offset) (include/cnerf.h, cnerf_cfg.drop_p):
+    one Philox block per 4 channels, counter index ((point * n_drop + d) * H + c) / 4, word c % 4 keeps iff >= round(p * 2^32).
+    stream_id 4 = coarse pass, 5 = fine pass, 6 = cnerf_field_forward."""
+    n_blocks = n_points * n_drop * H // 4
+    words = np.stack(_words(seed, offset, stream_id, n_blocks), -1)               # (blocks, 4)
+    thresh = min(int(p * 4294967296.0 + 0.5), 0xFFFFFFFF)
+    keep = (words >= np.uint32(thresh)).astype(np.uint8).reshape(n_points, n_drop, H)
+    return np.ascontiguousarray(keep.transpose(1, 0, 2))

@@ -174,9 +174,22 @@ def film_params(spec: FieldSpec, params: Dict[str, torch.Tensor], global_feature
 
 
 def field_mlp(spec: FieldSpec, params: Dict[str, torch.Tensor], feats: torch.Tensor,
-              global_feature: Optional[torch.Tensor], points: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """feats (B,N,C) -> rgb_sigma (B,N,4).  points (B,N,3) is needed by the input kinds that see the position."""
+              global_feature: Optional[torch.Tensor], points: Optional[torch.Tensor] = None,
+              drop: Optional[Tuple[float, torch.Tensor]] = None) -> torch.Tensor:
+    """feats (B,N,C) -> rgb_sigma (B,N,4).  points (B,N,3) is needed by the input kinds that see the position.
+    drop = (p, keep (n_drop, B, N, H) of 0/1): training-mode nn.Dropout(p) behind the sine of every FiLM / per-point FiLM / sine
+    layer (siren.py:158-159,175-176,197-198; residual blocks have none) with the keep decisions given -- F.dropout is
+    x * bernoulli(1 - p) / (1 - p) (ATen Dropout.cpp: noise.bernoulli_(1 - p).div_(1 - p); input * noise)."""
     H = params["final_layer.weight"].shape[1]
+    n_dropped = 0
+
+    def dropout(x):
+        nonlocal n_dropped
+        if drop is None:
+            return x
+        noise = drop[1][n_dropped].to(x.dtype) / (1 - drop[0])
+        n_dropped += 1
+        return x * noise
     freq, phase = film_params(spec, params, global_feature, H)
     x = feats
     if spec.input == "feat_xyz":
@@ -195,13 +208,13 @@ def field_mlp(spec: FieldSpec, params: Dict[str, torch.Tensor], feats: torch.Ten
             x = F.linear(x, params[pre + "layer.weight"], params[pre + "layer.bias"])
             fr = freq[:, f * H:(f + 1) * H].unsqueeze(1)
             ph = phase[:, f * H:(f + 1) * H].unsqueeze(1)
-            x = torch.sin(fr * x + ph)
+            x = dropout(torch.sin(fr * x + ph))
             f += 1
         elif kind == "pfilm":
             x = F.linear(x, params[pre + "layer.weight"], params[pre + "layer.bias"])
-            x = torch.sin(pfreq[..., i * H:(i + 1) * H] * x + pphase[..., i * H:(i + 1) * H])
+            x = dropout(torch.sin(pfreq[..., i * H:(i + 1) * H] * x + pphase[..., i * H:(i + 1) * H]))
         elif kind == "sine":
-            x = torch.sin(F.linear(x, params[pre + "layer.weight"], params[pre + "layer.bias"]))
+            x = dropout(torch.sin(F.linear(x, params[pre + "layer.weight"], params[pre + "layer.bias"])))
         elif kind == "res":
             h = torch.sin(F.linear(x, params[pre + "fc1.weight"], params[pre + "fc1.bias"]))
             h = F.linear(h, params[pre + "fc2.weight"], params[pre + "fc2.bias"])
@@ -214,14 +227,14 @@ def field_mlp(spec: FieldSpec, params: Dict[str, torch.Tensor], feats: torch.Ten
     return out
 
 
-def field_eval(spec: FieldSpec, params, fvol_cf, global_feature, points, explicit_lookup=False):
+def field_eval(spec: FieldSpec, params, fvol_cf, global_feature, points, explicit_lookup=False, drop=None):
     """fvol_cf: one (B,C,V,V,V) volume, or a list of them for the "pyramid" input kind."""
     look = trilinear_lookup_explicit if explicit_lookup else trilinear_lookup
     if isinstance(fvol_cf, (list, tuple)):
         feats = torch.cat([look(v, points) for v in fvol_cf], -1)
     else:
         feats = look(fvol_cf, points)
-    return field_mlp(spec, params, feats, global_feature, points), feats
+    return field_mlp(spec, params, feats, global_feature, points, drop), feats
 
 
 # ---------------------------------------------------------------------------------------
@@ -306,9 +319,12 @@ def render(variant: str, params: Dict[str, torch.Tensor], fvol_cf: torch.Tensor,
            noise_std: float, white_back: bool, last_back: bool, u_strat: torch.Tensor,
            eps_coarse: Optional[torch.Tensor] = None, u_fine: Optional[torch.Tensor] = None,
            eps_final: Optional[torch.Tensor] = None, explicit_lookup: bool = False,
-           forced_fine_z: Optional[torch.Tensor] = None) -> RenderOut:
+           forced_fine_z: Optional[torch.Tensor] = None, drop_p: float = 0.0,
+           drop_coarse: Optional[torch.Tensor] = None, drop_fine: Optional[torch.Tensor] = None) -> RenderOut:
     """forced_fine_z (B,P,S): test hook, replaces the resampled depths downstream of the resampling (teacher forcing,
-    the twin of cnerf_rng.fine_z); inds / cdf / the resampled depths are still returned in aux."""
+    the twin of cnerf_rng.fine_z); inds / cdf / the resampled depths are still returned in aux.
+    drop_p > 0 with drop_coarse / drop_fine (n_drop, B, P*S, H): the network in training mode with these dropout keep decisions
+    in its two forward calls (twin of cnerf_cfg.drop_p / cnerf_rng.drop_coarse, drop_fine)."""
     spec = FIELD_SPECS[variant]
     B, P = cam2world.shape[0], R * R
     aux: Dict[str, torch.Tensor] = {}
@@ -316,7 +332,8 @@ def render(variant: str, params: Dict[str, torch.Tensor], fvol_cf: torch.Tensor,
         dirs_cam = camera_ray_dirs(R, fov)
         z_lin, offset, z = stratified_depths(B, R, S, ray_start, ray_end, u_strat)
         pts, dirs_w, origins = coarse_world_points(cam2world, dirs_cam, z_lin, offset)
-    c_out, c_feat = field_eval(spec, params, fvol_cf, global_feature, pts.reshape(B, P * S, 3), explicit_lookup)
+    c_out, c_feat = field_eval(spec, params, fvol_cf, global_feature, pts.reshape(B, P * S, 3), explicit_lookup,
+                               (drop_p, drop_coarse) if drop_p > 0 else None)
     c_out = c_out.reshape(B, P, S, 4)
     aux.update(coarse_points=pts, coarse_z=z, coarse_feat=c_feat, coarse_rgb_sigma=c_out)
     if hierarchical:
@@ -327,7 +344,8 @@ def render(variant: str, params: Dict[str, torch.Tensor], fvol_cf: torch.Tensor,
             if forced_fine_z is not None:
                 fine_z = forced_fine_z.reshape(B, P, S)
             fpts = origins.reshape(B, 1, 1, 3) + dirs_w.unsqueeze(2) * fine_z.unsqueeze(-1)
-        f_out, _ = field_eval(spec, params, fvol_cf, global_feature, fpts.reshape(B, P * S, 3), explicit_lookup)
+        f_out, _ = field_eval(spec, params, fvol_cf, global_feature, fpts.reshape(B, P * S, 3), explicit_lookup,
+                              (drop_p, drop_fine) if drop_p > 0 else None)
         f_out = f_out.reshape(B, P, S, 4)
         all_out, all_z, sort_idx = merge_by_depth(f_out, c_out, fine_z, z)
         aux.update(coarse_weights=w, cdf=cdf, inds=inds, fine_z=fine_z, fine_points=fpts,

@@ -10,7 +10,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
-GOLDEN_NAMES = sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz") and not f.startswith("aux_"))
+ALL_FIXTURES = sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz") and not f.startswith("aux_"))
+# training-mode fixtures (dropout active, the keep decisions recorded): their own tests; the generic ones run the network in eval mode
+DROP_GOLDEN = [n for n in ALL_FIXTURES if "_drop_" in n]
+GOLDEN_NAMES = [n for n in ALL_FIXTURES if n not in DROP_GOLDEN]
 SMALL_GOLDEN = [n for n in GOLDEN_NAMES if n.endswith("_small") or n in ("short_fg_nohier", "short_fg_s40")]
 # fixtures the HIP path does not implement yet (the oracle and the host mirror do): per-point FiLM
 NOT_ON_GPU_YET = set()
@@ -48,6 +51,11 @@ class Golden:
 
     def grads(self, prefix="grad/siren."):
         return {k[len(prefix):]: self.d[k] for k in self.d.files if k.startswith(prefix)}
+
+    def oracle_dropout(self, T):
+        """Keyword arguments of oracle.render_oracle.render that put the network in this fixture's training mode."""
+        p = self.meta.get("drop_out", 0)
+        return dict(drop_p=p, drop_coarse=T(self.get("drop_coarse")), drop_fine=T(self.get("drop_fine"))) if p else {}
 
 
 @pytest.fixture(scope="session")

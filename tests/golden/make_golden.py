@@ -97,6 +97,17 @@ FIXTURES = {
     "short_fg_smooth": dict(variant="SHORTSIREN_FG", B=2, R=16, S=12, V=16, C=32, H=64, Z=48,
                             noise=0.0, clamp="softplus", white_back=True, last_back=False, seed=22, full=True,
                             grads=False, head=(3.0, 5.0, 0.5), smooth_from=3, amp=0.3),
+    # training mode with dropout behind every sine (siren.py:158-159,175-176,197-198): the keep decisions F.dropout drew are
+    # recorded (drop_coarse / drop_fine) like the other random draws
+    "short_fg_drop_small": dict(variant="SHORTSIREN_FG", B=2, R=12, S=10, V=10, C=32, H=64, Z=48,
+                                noise=0.5, clamp="relu", white_back=True, last_back=False, seed=23, full=True,
+                                grads=True, drop_out=0.25, head=(6.0, 20.0, 0.25)),   # (kept activations are scaled by 4/3 per layer)
+    "tallsiren_drop_small": dict(variant="TALLSIREN", B=1, R=10, S=8, V=8, C=32, H=64, Z=32,
+                                 noise=0.0, clamp="softplus", white_back=True, last_back=False, seed=24, full=True,
+                                 grads=True, drop_out=0.1),
+    "short_f_drop_small": dict(variant="SHORTSIREN_F", B=1, R=10, S=12, V=8, C=32, H=128, Z=32,
+                               noise=0.0, clamp="relu", white_back=False, last_back=True, seed=25, full=True,
+                               grads=True, drop_out=0.5),
 }
 
 # variants whose `z` is the bare feature volume (no global feature)
@@ -117,14 +128,16 @@ def build(name):
     variant = spec["variant"]
     # FG family: FiLMLayer(input_dim, hidden) eats the looked-up feature -> input_dim = C,
     # z_dim = width of the global feature.  Plain-sine families set input_dim = z_dim themselves.
+    p_drop = spec.get("drop_out", 0)
     if variant == "TALLSIREN":      # input = xyz; z_dim = width of the looked-up feature feeding the per-point mapping net
-        gen = ref_gen.ImplicitGenerator3d(variant, z_dim=C, input_dim=3, output_dim=4, hidden_dim=H)
+        gen = ref_gen.ImplicitGenerator3d(variant, z_dim=C, input_dim=3, output_dim=4, hidden_dim=H, drop_out=p_drop)
     elif variant in NO_GLOBAL:
-        gen = ref_gen.ImplicitGenerator3d(variant, z_dim=C, input_dim=C, output_dim=4, hidden_dim=H)
+        gen = ref_gen.ImplicitGenerator3d(variant, z_dim=C, input_dim=C, output_dim=4, hidden_dim=H, drop_out=p_drop)
     else:
-        gen = ref_gen.ImplicitGenerator3d(variant, z_dim=Z, input_dim=spec.get("input_dim", C), output_dim=4, hidden_dim=H)
+        gen = ref_gen.ImplicitGenerator3d(variant, z_dim=Z, input_dim=spec.get("input_dim", C), output_dim=4, hidden_dim=H,
+                                          drop_out=p_drop)
     gen.set_device(torch.device("cpu"))
-    gen.eval()
+    gen.train(bool(p_drop))         # dropout is active in training mode only
     # Default init gives near-zero densities (an all-background image pins nothing): scale the head so
     # that sigma spans both signs at O(1..10) and colours leave the sigmoid's linear range.  The scaled
     # values are stored in the fixture like every other parameter.
@@ -147,10 +160,20 @@ def build(name):
     cam2world = ref_vr.create_cam2world_matrix(origins, "y", device=torch.device("cpu")).float()
 
     rec = {"rand": [], "randn": [], "feat": [], "siren_in": [], "siren_out": [], "weights": [],
-           "z_in": [], "cdf": [], "inds": [], "fine_z": [], "sort_idx": []}
+           "z_in": [], "cdf": [], "inds": [], "fine_z": [], "sort_idx": [], "drop": []}
 
     o_rand, o_randn, o_gs, o_ss, o_sort = torch.rand, torch.randn, F.grid_sample, torch.searchsorted, torch.sort
     o_fi, o_sp = ref_gen.fancy_integration, ref_gen.sample_pdf
+    o_drop = F.dropout
+
+    def w_drop(x, p=0.5, training=True, inplace=False):
+        # nn.Dropout.forward -> F.dropout: run the reference's call and read the keep decisions off its output
+        # (y = x * keep / (1 - p); sin(.) == 0 exactly does not occur in these fixtures, asserted below)
+        y = o_drop(x, p, training, inplace)
+        if training and p > 0:
+            assert (x != 0).all()
+            rec["drop"].append((y != 0).detach().clone())
+        return y
 
     def w_rand(*a, **k):
         t = o_rand(*a, **k); rec["rand"].append(t.detach().clone()); return t
@@ -182,6 +205,7 @@ def build(name):
     hook = gen.siren.register_forward_hook(siren_hook)
     torch.rand, torch.randn, F.grid_sample, torch.searchsorted, torch.sort = w_rand, w_randn, w_gs, w_ss, w_sort
     ref_gen.fancy_integration, ref_gen.sample_pdf = w_fi, w_sp
+    F.dropout = w_drop
     try:
         z = fvol if variant in NO_GLOBAL else ((pyr if pyr is not None else fvol), glob)
         kw = dict(clamp_mode=spec["clamp"], nerf_noise=spec["noise"], white_back=spec["white_back"],
@@ -192,6 +216,7 @@ def build(name):
     finally:
         torch.rand, torch.randn, F.grid_sample, torch.searchsorted, torch.sort = o_rand, o_randn, o_gs, o_ss, o_sort
         ref_gen.fancy_integration, ref_gen.sample_pdf = o_fi, o_sp
+        F.dropout = o_drop
         hook.remove()
 
     out = {}
@@ -222,6 +247,11 @@ def build(name):
         if spec["noise"] != 0:
             out["eps_final"] = rec["randn"][0].numpy().reshape(B, R * R, S)
 
+    if p_drop:
+        n_drop = len(rec["drop"]) // (2 if hier else 1)      # one F.dropout call per FiLM / sine layer and forward call
+        out["drop_coarse"] = np.stack([m.numpy().reshape(B, R * R * S, H) for m in rec["drop"][:n_drop]]).astype(np.uint8)
+        if hier:
+            out["drop_fine"] = np.stack([m.numpy().reshape(B, R * R * S, H) for m in rec["drop"][n_drop:]]).astype(np.uint8)
     out["pixels"] = pixels.detach().numpy()
     out["depth"] = depth.detach().numpy()
     out["coarse_rgb_sigma"] = rec["siren_out"][0].numpy().reshape(B, R * R, S, 4)

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import GOLDEN_NAMES as ALL_GOLDEN, SMALL_GOLDEN as ALL_SMALL, NOT_ON_GPU_YET, NO_BACKWARD_YET, scaled_err
+from conftest import GOLDEN_NAMES as ALL_GOLDEN, SMALL_GOLDEN as ALL_SMALL, DROP_GOLDEN, NOT_ON_GPU_YET, NO_BACKWARD_YET, scaled_err
 
 GOLDEN_NAMES = [n for n in ALL_GOLDEN if n not in NOT_ON_GPU_YET]
 SMALL_GOLDEN = [n for n in ALL_SMALL if n not in NOT_ON_GPU_YET]
@@ -34,12 +34,13 @@ def make_generator(g, dev):
     import cnerf_amd
     from cnerf_amd.generators import ImplicitGenerator3d
     m = g.meta
+    dp = m.get("drop_out", 0)
     if m["variant"] == "TALLSIREN":
-        gen = ImplicitGenerator3d(m["variant"], z_dim=m["C"], input_dim=3, output_dim=4, hidden_dim=m["H"])
+        gen = ImplicitGenerator3d(m["variant"], z_dim=m["C"], input_dim=3, output_dim=4, hidden_dim=m["H"], drop_out=dp)
     elif m["has_global"]:
-        gen = ImplicitGenerator3d(m["variant"], z_dim=m["Z"], input_dim=m.get("input_dim", m["C"]), output_dim=4, hidden_dim=m["H"])
+        gen = ImplicitGenerator3d(m["variant"], z_dim=m["Z"], input_dim=m.get("input_dim", m["C"]), output_dim=4, hidden_dim=m["H"], drop_out=dp)
     else:
-        gen = ImplicitGenerator3d(m["variant"], z_dim=m["C"], input_dim=m["C"], output_dim=4, hidden_dim=m["H"])
+        gen = ImplicitGenerator3d(m["variant"], z_dim=m["C"], input_dim=m["C"], output_dim=4, hidden_dim=m["H"], drop_out=dp)
     sd = {k[len("param/"):]: torch.from_numpy(g[k]) for k in g.d.files if k.startswith("param/")}
     gen.load_state_dict(sd, strict=True)
     gen.to(dev)
@@ -433,7 +434,7 @@ def reference_grad_noise_floor(g):
         out = O.render(m["variant"], params, fvol, glob, T(g["cam2worlds"]), m["R"], m["fov"], m["ray_start"], m["ray_end"],
                        m["S"], m["hierarchical"], m["clamp"], m["noise"], m["white_back"], m["last_back"], T(g["u_strat"]),
                        T(g.get("eps_coarse")), T(g.get("u_fine")), T(g.get("eps_final")),
-                       forced_fine_z=T(g.get("fine_z")) if m["hierarchical"] else None)
+                       forced_fine_z=T(g.get("fine_z")) if m["hierarchical"] else None, **g.oracle_dropout(T))
     finally:
         torch.set_default_dtype(torch.float32)
     loss = out.pixels.square().mean() + out.depth.mean()
@@ -1138,3 +1139,83 @@ def test_in_kernel_philox_equals_injected_draws(dev, precision):
     with torch.no_grad():
         p3, _ = gen((fvol, glob), cam, R, 49.13, 0.25, 1.95, S, True, clamp_mode="relu", nerf_noise=0.0)
     assert torch.equal(p1, p3)
+
+
+def _dropout_rng(g, dev):
+    rng = {k: G(g.get(k), dev) for k in ("u_strat", "eps_coarse", "u_fine", "eps_final", "drop_coarse", "drop_fine") if g.get(k) is not None}
+    if g.meta["hierarchical"]:
+        rng["fine_z"] = G(g["fine_z"], dev)
+    return rng
+
+
+@pytest.mark.parametrize("name", DROP_GOLDEN)
+def test_dropout_training_mode_matches_reference(golden, dev, name):
+    """The reference in training mode with drop_out > 0 (siren.py:158-159,175-176,197-198), its own F.dropout keep decisions
+    injected (cnerf_rng.drop_coarse / drop_fine), fine depths forced: field outputs, image, depth at the 1e-4 gate and every
+    gradient at the tolerance of test_backward_teacher_forced -- FiLM, per-point FiLM (TALLSIREN) and plain-sine networks."""
+    g = golden(name)
+    m = g.meta
+    gen = make_generator(g, dev)
+    gen.train()
+    z, vleaves, glob = make_z(g, dev, requires_grad=True)
+    aux = {}
+    pixels, depth = gen(z, G(g["cam2worlds"], dev), m["R"], m["fov"], m["ray_start"], m["ray_end"], m["S"], m["hierarchical"],
+                        clamp_mode=m["clamp"], nerf_noise=m["noise"], white_back=m["white_back"], last_back=m["last_back"],
+                        _rng=_dropout_rng(g, dev), _aux=aux)
+    for k in ("coarse_rgb_sigma", "fine_rgb_sigma"):
+        assert rgb_sigma_err(aux[k], g[k]) < TOL, k
+    assert scaled_err(pixels.detach().cpu().numpy(), g["pixels"]) < TOL
+    assert scaled_err(depth.detach().cpu().numpy(), g["depth"]) < TOL
+    loss = pixels.square().mean() + depth.mean()
+    loss.backward()
+    floor = reference_grad_noise_floor(g)
+    tol = lambda k: max(2e-3, 2.5 * floor[k])
+    assert scaled_err(vleaves[0].grad.cpu().numpy(), g["grad_feature_volume"]) < tol("feature_volume")
+    if glob is not None:
+        assert scaled_err(glob.grad.cpu().numpy(), g["grad_global_feature"]) < tol("global_feature")
+    for k, p in gen.named_parameters():
+        assert p.grad is not None, k
+        assert scaled_err(p.grad.cpu().numpy(), g["grad/" + k]) < tol(k), k
+    # eval mode drops nothing: a different image
+    gen.eval()
+    with torch.no_grad():
+        px_eval, _ = gen(z, G(g["cam2worlds"], dev), m["R"], m["fov"], m["ray_start"], m["ray_end"], m["S"], m["hierarchical"],
+                         clamp_mode=m["clamp"], nerf_noise=m["noise"], white_back=m["white_back"], last_back=m["last_back"],
+                         _rng=_dropout_rng(g, dev))
+    assert (px_eval - pixels.detach()).abs().max().item() > 1e-3
+
+
+@pytest.mark.parametrize("name", DROP_GOLDEN)
+def test_dropout_in_kernel_decisions_equal_their_numpy_twin(golden, dev, name):
+    """Without injected bytes the kernels draw the keep decisions themselves (Philox4x32-10 under cnerf_cfg.philox_seed / _offset,
+    stream 4 coarse / 5 fine, one block per 4 channels).  oracle/philox.py::dropout_keep restates that layout: injecting its bytes
+    must reproduce the in-kernel run bit for bit, forward and backward; the keep rate is 1 - p."""
+    from oracle import philox as P
+    g = golden(name)
+    m = g.meta
+    gen = make_generator(g, dev)
+    gen.train()
+    B, npi, H, p = m["B"], m["R"] * m["R"] * m["S"], m["H"], m["drop_out"]
+    n_drop = sum(1 for k in gen.siren.spec.layers if k != "res")
+    seed, offset = 0x1234567890ABCDEF, 77
+    keep = {k: P.dropout_keep(seed, offset, sid, B * npi, n_drop, H, p) for k, sid in (("drop_coarse", 4), ("drop_fine", 5))}
+    assert abs(keep["drop_coarse"].mean() - (1 - p)) < 5e-3
+    base = {k: v for k, v in _dropout_rng(g, dev).items() if not k.startswith("drop_")}
+    runs = []
+    for rng in (dict(base, drop=(p, (seed, offset))),
+                dict(base, drop=(p, (seed + 1, offset)), **{k: G(v.reshape(n_drop, B, npi, H), dev) for k, v in keep.items()})):
+        z, vleaves, glob = make_z(g, dev, requires_grad=True)
+        gen.zero_grad()
+        px, dp = gen(z, G(g["cam2worlds"], dev), m["R"], m["fov"], m["ray_start"], m["ray_end"], m["S"], m["hierarchical"], clamp_mode=m["clamp"],
+                     nerf_noise=m["noise"], white_back=m["white_back"], last_back=m["last_back"], _rng=rng)
+        (px.square().mean() + dp.mean()).backward()
+        runs.append((px.detach().clone(), dp.detach().clone(), {k: q.grad.clone() for k, q in gen.named_parameters()}))
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+    for k in runs[0][2]:      # (weight gradients are reduced with float atomics: order-dependent in the last bits)
+        assert scaled_err(runs[0][2][k].cpu().numpy(), runs[1][2][k].cpu().numpy()) < 1e-5, k
+    # another counter offset: other decisions
+    z, _, _ = make_z(g, dev)
+    with torch.no_grad():
+        px2, _ = gen(z, G(g["cam2worlds"], dev), m["R"], m["fov"], m["ray_start"], m["ray_end"], m["S"], m["hierarchical"], clamp_mode=m["clamp"],
+                     nerf_noise=m["noise"], white_back=m["white_back"], last_back=m["last_back"], _rng=dict(base, drop=(p, (seed, offset + 1))))
+    assert not torch.equal(px2, runs[0][0])

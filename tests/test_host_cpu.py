@@ -107,8 +107,12 @@ def test_unknown_variant_and_dropout():
         ImplicitGenerator3d("TALLSIREN_dg", 8, 32, 4, 64)      # a name the reference's configs still mention
     gen = ImplicitGenerator3d("SHORTSIREN_FG", 8, 32, 4, 64, drop_out=0.1)
     gen.train()
-    with pytest.raises(NotImplementedError):
+    gen.siren.check_supported()                    # dropout runs in the fp32 kernels ...
+    gen.siren.precision = "fp16x3"
+    with pytest.raises(NotImplementedError):       # ... and only there
         gen.siren.check_supported()
+    gen.eval()
+    gen.siren.check_supported()                    # eval mode: nothing is dropped, any precision
 
 
 def test_philox_known_answers():

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import GOLDEN_NAMES, SMALL_GOLDEN, scaled_err
+from conftest import GOLDEN_NAMES, SMALL_GOLDEN, DROP_GOLDEN, scaled_err
 from oracle import render_oracle as O
 
 TOL = 2e-5
@@ -25,7 +25,7 @@ def run_oracle(g, explicit=False):
     return O.render(m["variant"], params, vols, T(g.get("global_feature")), T(g["cam2worlds"]),
                     m["R"], m["fov"], m["ray_start"], m["ray_end"], m["S"], m["hierarchical"], m["clamp"], m["noise"],
                     m["white_back"], m["last_back"], T(g["u_strat"]), T(g.get("eps_coarse")), T(g.get("u_fine")),
-                    T(g.get("eps_final")), explicit_lookup=explicit)
+                    T(g.get("eps_final")), explicit_lookup=explicit, **g.oracle_dropout(T))
 
 
 def guard_band_mask(cdf, u, band=2e-6):
@@ -33,8 +33,9 @@ def guard_band_mask(cdf, u, band=2e-6):
     return (np.abs(u[..., :, None] - cdf[..., None, :]) > band).all(-1)
 
 
-@pytest.mark.parametrize("name", GOLDEN_NAMES)
+@pytest.mark.parametrize("name", GOLDEN_NAMES + DROP_GOLDEN)
 def test_render_matches_reference(golden, name):
+    """(the *_drop_* fixtures: the reference in training mode with drop_out > 0, its F.dropout keep decisions injected)"""
     g = golden(name)
     out = run_oracle(g)
     assert scaled_err(out.pixels, g["pixels"]) < TOL
@@ -52,6 +53,36 @@ def test_render_matches_reference(golden, name):
         assert bad.mean() < 1e-3
         sbad = out.aux["sort_idx"].numpy() != g["sort_idx"]
         assert sbad.mean() < 1e-3
+
+
+@pytest.mark.parametrize("name", [n for n in SMALL_GOLDEN + DROP_GOLDEN])
+def test_gradients_match_reference(golden, name):
+    """Autograd through the oracle against the reference's own gradients of pixels.square().mean() + depth.mean() (stored by
+    make_golden.py): every field parameter, the feature volume(s), the global feature -- the oracle is the gradient reference of
+    the GPU tests (ragged shapes, H = 256), so its backward is pinned too, dropout fixtures included."""
+    g = golden(name)
+    if "loss" not in g:
+        pytest.skip("fixture stores no gradients")
+    m = g.meta
+    params = {k: T(v).clone().requires_grad_(True) for k, v in g.params().items()}
+    vols = g.volumes()
+    vleaves = [T(v).clone().requires_grad_(True) for v in (vols if isinstance(vols, list) else [vols])]
+    glob = T(g.get("global_feature"))
+    if glob is not None:
+        glob = glob.clone().requires_grad_(True)
+    out = O.render(m["variant"], params, vleaves if isinstance(vols, list) else vleaves[0], glob, T(g["cam2worlds"]), m["R"], m["fov"],
+                   m["ray_start"], m["ray_end"], m["S"], m["hierarchical"], m["clamp"], m["noise"], m["white_back"], m["last_back"],
+                   T(g["u_strat"]), T(g.get("eps_coarse")), T(g.get("u_fine")), T(g.get("eps_final")), **g.oracle_dropout(T))
+    loss = out.pixels.square().mean() + out.depth.mean()
+    assert abs(loss.item() - float(g["loss"])) < 1e-5 * max(1.0, abs(float(g["loss"])))
+    leaves = vleaves + ([glob] if glob is not None else []) + list(params.values())
+    grads = torch.autograd.grad(loss, leaves, allow_unused=True)
+    want = [g["grad_feature_volume"]] + [g[f"grad_feature_volume_l{i}"] for i in range(1, len(vleaves))]
+    want += [g["grad_global_feature"]] if glob is not None else []
+    want += [g["grad/siren." + k] for k in params]
+    for got, w, leaf in zip(grads, want, leaves):
+        got = torch.zeros_like(leaf) if got is None else got
+        assert scaled_err(got.numpy(), w) < 1e-4
 
 
 @pytest.mark.parametrize("name", SMALL_GOLDEN)
