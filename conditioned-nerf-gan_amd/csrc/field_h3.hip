@@ -157,8 +157,21 @@ static hipError_t pack_impl(const float* w, int n_out, int K_real, int OT, bool 
 // bias / freq / phase of channels (r, r+1) of output tile t, lane half h, from LDS.  Issued one step ahead of their use:
 // an LDS read that is consumed at once stalls the wave for the full ds latency (lgkmcnt retires in order, behind the
 // A-fragment prefetches).
+// Folded FiLM (CNERF_H3_FOLD, default on).  arg = freq (acc / S + b) + phase is affine in the accumulator, and v_sin_f32 takes
+// revolutions, so per image, matrix and channel three constants are prepared in LDS (in double, once per image and block):
+//     M = freq / (2 pi S) = Mh + Ml (two floats),   K = (freq b + phase) / (2 pi)
+// and the epilogue is  n = rint(acc Mh);  u = fma(acc, Ml, fma(acc, Mh, -n)) + K;  sin(2 pi u)  -- 5 vector ops + v_sin where the
+// unfolded form (bias fma, FiLM mul, add, two-term Cody-Waite reduction by 2 pi, scale to revolutions) takes 8.  It is also the
+// more exact of the two: acc Mh - n is a single-rounding fma of magnitude <= 1/2, the argument never exists rounded at its
+// full magnitude (|arg| ~ 200 rad, ulp 1.5e-5 rad), so the result is within ~2e-7 rev of the exact affine map, where the
+// reference's own fp32 sequence (x = acc + b, freq x, + phase: three roundings at full magnitude) is ~1e-5 rad from it.
+// A plain sine layer is freq = 1, phase = 0.  The second matrix of a residual block (x + W2 y + b2) keeps the unfolded form.
+#ifndef CNERF_H3_FOLD
+#define CNERF_H3_FOLD 1
+#endif
+
 struct FilmPair {
-    f32x2 fr, ph, bs;
+    f32x2 fr, ph, bs;       // FOLD (non-residual matrices): fr = Mh, ph = Ml, bs = K
 };
 __device__ __forceinline__ FilmPair film_pair_load(const float* lbias, const float* lfr, const float* lph, int t, int h, int r) {
     FilmPair f;
@@ -203,9 +216,22 @@ template <int STORE, bool RESID, int PHASE = 0>
 __device__ __forceinline__ void film_split_pair(const f32x16& acc, float inv_s, const FilmPair& f, int t, int h, int r, Split2* out2,
                                                 ActStore& st) {
     float a0 = 0.0f, a1 = 0.0f;
+    constexpr bool FOLD = CNERF_H3_FOLD && !RESID;
+    if (FOLD) {             // a0, a1 = the argument in revolutions, reduced to about [-1/2, 1/2] + K
+        if (PHASE != 2) {
+            const float n0 = __builtin_rintf(acc[r] * f.fr[0]);
+            a0 = __builtin_fmaf(acc[r], f.ph[0], __builtin_fmaf(acc[r], f.fr[0], -n0)) + f.bs[0];
+        }
+        if (PHASE != 1) {
+            const float n1 = __builtin_rintf(acc[r + 1] * f.fr[1]);
+            a1 = __builtin_fmaf(acc[r + 1], f.ph[1], __builtin_fmaf(acc[r + 1], f.fr[1], -n1)) + f.bs[1];
+        }
+    } else {
     if (PHASE != 2) a0 = __builtin_fmaf(acc[r], inv_s, f.bs[0]);
     if (PHASE != 1) a1 = __builtin_fmaf(acc[r + 1], inv_s, f.bs[1]);
-    if (RESID) {
+    }
+    if (FOLD) {
+    } else if (RESID) {
         const uint32_t xh = out2[r >> 3].p[0][(r & 7) >> 1], xl = PARTS == 2 ? out2[r >> 3].p[PARTS - 1][(r & 7) >> 1] : 0u;
         if (PHASE != 2) a0 = (half_lo(xh) + half_lo(xl)) + a0;
         if (PHASE != 1) a1 = (half_hi(xh) + half_hi(xl)) + a1;
@@ -214,9 +240,18 @@ __device__ __forceinline__ void film_split_pair(const f32x16& acc, float inv_s, 
         if (PHASE != 1) a1 = f.fr[1] * a1 + f.ph[1];
     }
     float v0 = 0.0f, v1 = 0.0f;
+    auto sin_of = [](float x) { return FOLD ? __builtin_amdgcn_sinf(x) : sin_2pi_reduced_hw(x); };
+    auto sincos_of = [](float x, float& sn, float& cs) {
+        if (FOLD) {
+            sn = __builtin_amdgcn_sinf(x);
+            cs = __builtin_amdgcn_cosf(x);
+        } else {
+            sincos_2pi_reduced_hw(x, sn, cs);
+        }
+    };
     if (PHASE == 1) {
-        if (STORE) sincos_2pi_reduced_hw(a0, st.pv, st.pc);
-        else st.pv = sin_2pi_reduced_hw(a0);
+        if (STORE) sincos_of(a0, st.pv, st.pc);
+        else st.pv = sin_of(a0);
         return;
     }
     if (STORE) {
@@ -225,9 +260,9 @@ __device__ __forceinline__ void film_split_pair(const f32x16& acc, float inv_s, 
             v0 = st.pv;
             c0 = st.pc;
         } else {
-            sincos_2pi_reduced_hw(a0, v0, c0);
+            sincos_of(a0, v0, c0);
         }
-        sincos_2pi_reduced_hw(a1, v1, c1);
+        sincos_of(a1, v1, c1);
         if ((r & 2) == 0) {
             st.ks[0] = v0;
             st.ks[1] = v1;
@@ -245,8 +280,8 @@ __device__ __forceinline__ void film_split_pair(const f32x16& acc, float inv_s, 
             *reinterpret_cast<u32x2_*>(st.blk_c + (t * 4 + (r >> 2)) * 256) = u32x2_{pk_f16(st.kc[0], st.kc[1]), pk_f16(c0, c1)};
         }
     } else {
-        v0 = PHASE == 2 ? st.pv : sin_2pi_reduced_hw(a0);
-        v1 = sin_2pi_reduced_hw(a1);
+        v0 = PHASE == 2 ? st.pv : sin_of(a0);
+        v1 = sin_of(a1);
     }
     Split2& d = out2[r >> 3];
     switch (r & 7) {
@@ -447,6 +482,9 @@ __global__ __launch_bounds__(256) void field_h3_kernel(FieldArgs a) {
     const float* lds_zeros = lds_ones + H;
     float* lds_freq = lds_bias + a.bias_floats + 2 * H;                             // FiLM vectors of the block's image
     float* lds_phase = lds_freq + a.film_stride;
+    float* lds_mh = lds_phase + a.film_stride;                       // folded FiLM constants of the block's image: n_mats x H each
+    float* lds_ml = lds_mh + (size_t)a.n_mats * H;
+    float* lds_k = lds_ml + (size_t)a.n_mats * H;
     const float* lds_inv_s = lds_bias + (size_t)a.n_mats * H + 4;    // 1/S per matrix (a residual block has two), then the head's
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -505,12 +543,32 @@ __global__ __launch_bounds__(256) void field_h3_kernel(FieldArgs a) {
         const long long nn = tp.nn;
         const bool valid = tp.valid;
         BSTAMP(0);
-        if (b != staged_b && a.freq) {                              // block-uniform
+        if (b != staged_b && (a.freq || (CNERF_H3_FOLD && staged_b < 0))) {     // block-uniform
             __syncthreads();                                        // nobody still reads the previous image's vectors
-            for (int i = threadIdx.x; i < a.film_stride; i += 256) {
-                lds_freq[i] = a.freq[(size_t)b * a.film_stride + i];
-                lds_phase[i] = a.phase[(size_t)b * a.film_stride + i];
+            if (a.freq)
+                for (int i = threadIdx.x; i < a.film_stride; i += 256) {
+                    lds_freq[i] = a.freq[(size_t)b * a.film_stride + i];
+                    lds_phase[i] = a.phase[(size_t)b * a.film_stride + i];
+                }
+#if CNERF_H3_FOLD
+            for (int i = threadIdx.x; i < a.n_mats * H; i += 256) {
+                const int mm = i / H, ch = i - mm * H;
+                int film = -1, mats = 0, films = 0;                 // FiLM index of matrix mm (-1: plain sine / residual half)
+                for (int l = 0; l < a.L; ++l) {
+                    const int kind = a.layer_kind[l];
+                    if (kind == CNERF_LAYER_FILM && mats == mm) film = films;
+                    films += kind == CNERF_LAYER_FILM;
+                    mats += kind == CNERF_LAYER_RES ? 2 : 1;
+                }
+                const double fr = film >= 0 ? (double)a.freq[(size_t)b * a.film_stride + (size_t)film * H + ch] : 1.0;
+                const double ph = film >= 0 ? (double)a.phase[(size_t)b * a.film_stride + (size_t)film * H + ch] : 0.0;
+                const double M = fr * (double)lds_inv_s[mm] * 0.15915494309189533577;
+                const float mh = (float)M;
+                lds_mh[i] = mh;
+                lds_ml[i] = (float)(M - (double)mh);
+                lds_k[i] = (float)((fr * (double)lds_bias[i] + ph) * 0.15915494309189533577);
             }
+#endif
             staged_b = b;
             __syncthreads();                                        // (once per image: not every unit starts with a barrier)
         }
@@ -579,7 +637,10 @@ __global__ __launch_bounds__(256) void field_h3_kernel(FieldArgs a) {
             const bool film = a.layer_kind[0] == CNERF_LAYER_FILM;
             const float inv_s = lds_inv_s[0];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) film_split<STORE, false>(acc0[t], inv_s, bias, film ? lfr : lds_ones, film ? lph : lds_zeros, t, h, &x[2 * t], st);
+            for (int t = 0; t < NT; ++t) {
+                if (CNERF_H3_FOLD) film_split<STORE, false>(acc0[t], inv_s, lds_k, lds_mh, lds_ml, t, h, &x[2 * t], st);
+                else film_split<STORE, false>(acc0[t], inv_s, bias, film ? lfr : lds_ones, film ? lph : lds_zeros, t, h, &x[2 * t], st);
+            }
             if (STORE == STORE_F32) {
                 st.row_h += act_layer;
                 st.row_c += act_layer;
@@ -599,9 +660,14 @@ __global__ __launch_bounds__(256) void field_h3_kernel(FieldArgs a) {
         // One matrix: out[t] = epilogue(W[t] in) for the NT output tiles, the epilogue of tile t-1 pipelined under the MFMAs
         // of tile t.  RESID: `out` is the residual block's input x and is updated in place.
         int m = 1;                                                   // matrix counter (scales, activation slabs)
-        auto matrix = [&](const Split2* in, Split2* out, auto resid_tag, const float* fr_l, const float* ph_l) {
+        auto matrix = [&](const Split2* in, Split2* out, auto resid_tag, const float* fr_arg, const float* ph_arg) {
             constexpr bool RESID = decltype(resid_tag)::value;
             const float inv_s = lds_inv_s[m];
+            // folded constants of matrix m stand in for (bias, freq, phase) where the epilogue is the affine-then-sine one
+            constexpr bool FOLDED = CNERF_H3_FOLD && !RESID;
+            const float* bias_l = FOLDED ? lds_k + (size_t)m * H : bias;
+            const float* fr_l = FOLDED ? lds_mh + (size_t)m * H : fr_arg;
+            const float* ph_l = FOLDED ? lds_ml + (size_t)m * H : ph_arg;
             f32x16 acc_prev;
             FilmPair fp;
             [[maybe_unused]] FilmPair fp_done;            // (CNERF_H3_BALANCE only)
@@ -618,7 +684,7 @@ __global__ __launch_bounds__(256) void field_h3_kernel(FieldArgs a) {
                     if (t > 0 && c < 16) {
                         if (!(c & 1)) {
                             if (c >= 2) film_split_pair<STORE, RESID, 2>(acc_prev, inv_s, fp_done, t - 1, h, c - 2, &out[2 * (t - 1)], st);
-                            fp = film_pair_load(bias, fr_l, ph_l, t - 1, h, c);
+                            fp = film_pair_load(bias_l, fr_l, ph_l, t - 1, h, c);
                         } else {
                             film_split_pair<STORE, RESID, 1>(acc_prev, inv_s, fp, t - 1, h, c - 1, &out[2 * (t - 1)], st);
                             fp_done = fp;
@@ -626,7 +692,7 @@ __global__ __launch_bounds__(256) void field_h3_kernel(FieldArgs a) {
                     }
 #else
                     if (t > 0 && c < 16) {                     // epilogue of tile t-1, one pair of elements per two chunks
-                        if (!(c & 1)) fp = film_pair_load(bias, fr_l, ph_l, t - 1, h, c);
+                        if (!(c & 1)) fp = film_pair_load(bias_l, fr_l, ph_l, t - 1, h, c);
                         else film_split_pair<STORE, RESID>(acc_prev, inv_s, fp, t - 1, h, c - 1, &out[2 * (t - 1)], st);
                     }
 #endif
@@ -637,12 +703,12 @@ __global__ __launch_bounds__(256) void field_h3_kernel(FieldArgs a) {
                 if (t > 0 && KCH < 16) {                       // narrow networks: the rest of tile t-1's elements
 #pragma unroll
                     for (int r = KCH; r < 16; r += 2)
-                        film_split_pair<STORE, RESID>(acc_prev, inv_s, film_pair_load(bias, fr_l, ph_l, t - 1, h, r), t - 1, h, r,
+                        film_split_pair<STORE, RESID>(acc_prev, inv_s, film_pair_load(bias_l, fr_l, ph_l, t - 1, h, r), t - 1, h, r,
                                                       &out[2 * (t - 1)], st);
                 }
                 acc_prev = acc;
             }
-            film_split<STORE, RESID>(acc_prev, inv_s, bias, fr_l, ph_l, NT - 1, h, &out[2 * (NT - 1)], st);
+            film_split<STORE, RESID>(acc_prev, inv_s, bias_l, fr_l, ph_l, NT - 1, h, &out[2 * (NT - 1)], st);
             if (STORE == STORE_F32) {
                 st.row_h += act_layer;
                 st.row_c += act_layer;
@@ -716,7 +782,9 @@ constexpr size_t LDS_LIMIT = 160 * 1024;
 template <int NT>
 static size_t h3_lds_bytes(const FieldArgs& a, int slots) {
     // weight units (32 KiB each at H = 256), biases + scales, ones / zeros, freq / phase of one image
-    return slots * (size_t)H3Lds<NT>::FRAGS * 16 + ((size_t)a.bias_floats + 2 * NT * 32 + 2 * (size_t)a.film_stride) * 4;
+    // ... and the folded FiLM constants (3 per matrix and channel)
+    return slots * (size_t)H3Lds<NT>::FRAGS * 16 +
+           ((size_t)a.bias_floats + 2 * NT * 32 + 2 * (size_t)a.film_stride + 3 * (size_t)a.n_mats * NT * 32) * 4;
 }
 
 template <int NT, int STORE, bool PAIRED, bool HAS_RES>

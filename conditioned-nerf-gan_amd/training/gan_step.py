@@ -91,10 +91,21 @@ class GanTrainer:
         self.alpha = min(1.0, (step - step_last_upsample) / self.metadata["fade_steps"]) if self.metadata["fade_steps"] > 0 else 1.0
         self.metadata["nerf_noise"] = max(0.0, 1.0 - step / 5000.0)
 
+    def _encode(self, voxels):
+        """The 3D U-Net.  metadata["encoder_autocast"] = "bf16" / "fp16" runs its convolutions under torch.autocast, as the
+        reference's GPU training does with the whole step (utils.py:327,643: autocast + GradScaler; bf16 needs no scaler); the
+        render path takes fp32 volumes either way."""
+        amp = self.metadata.get("encoder_autocast")
+        if not amp:
+            return self.encoder_ddp(voxels)
+        with torch.autocast(self.device.type, dtype=torch.bfloat16 if amp == "bf16" else torch.float16):
+            out = self.encoder_ddp(voxels)
+        return tuple(o.float() for o in out) if isinstance(out, (tuple, list)) else out.float()
+
     def _render(self, voxels, cams, chunk=0, phase="g"):
         z = self._z.get(chunk) if phase == "d" else self._z.pop(chunk, None)      # encoder output kept by step() (see there)
         if z is None:
-            z = self.encoder_ddp(voxels)
+            z = self._encode(voxels)
         extra = {"_rng": self.render_rng(chunk, phase)} if self.render_rng is not None else {}
         return self.generator_ddp(z, cams, **self.metadata, **extra)
 
@@ -197,7 +208,7 @@ class GanTrainer:
                 if self.ddp and i == len(chunks) - 1:
                     continue
                 with (self.encoder_ddp.no_sync() if self.ddp else contextlib.nullcontext()):
-                    self._z[i] = self.encoder_ddp(voxels[c])
+                    self._z[i] = self._encode(voxels[c])
         if self.metadata["enable_discriminator"]:
             self.train_discriminator(sample)
         self.train_generator(sample)

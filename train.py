@@ -33,6 +33,8 @@ def main():
     ap.add_argument("--precision", default="fp32", choices=["fp32", "fp16x3"], help="arithmetic of the forward render")
     ap.add_argument("--backward-precision", default="fp32", choices=["fp32", "fp16"],
                     help="gradient GEMMs of the render backward: exact fp32 MFMA, or fp16 operands with fp32 sums")
+    ap.add_argument("--encoder-autocast", default=None, choices=["bf16", "fp16"],
+                    help="run the 3D U-Net's convolutions under torch.autocast (the reference trains under fp16 autocast)")
     ap.add_argument("--no-miopen-find", action="store_true",
                     help="keep MIOpen's immediate-mode kernel choice for the Conv3d/Conv2d layers (fast start, 3x slower steps)")
     ap.add_argument("--checkpoint-dir", default=None, help="write <step>.tar (the reference's checkpoint keys) after the last step")
@@ -61,6 +63,7 @@ def main():
     md = default_metadata(args.img_size, args.num_steps, args.batch, args.batch_split, args.siren_type, args.hidden)
     md["render_precision"] = args.precision
     md["backward_precision"] = args.backward_precision
+    md["encoder_autocast"] = args.encoder_autocast
     md["miopen_find"] = not args.no_miopen_find
     md["encoder_channels_last"] = bool(int(os.environ.get("CNERF_ENCODER_CHANNELS_LAST", "0")))
     trainer = GanTrainer(md, dev, ddp=world > 1)
