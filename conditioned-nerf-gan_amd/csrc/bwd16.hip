@@ -216,9 +216,16 @@ hipError_t launch_weight_grad16(int cnt, long long tiles_per_image, int n_rows, 
 //   * stored g16[m]: one scale S_m per slab for the whole call (the weight-gradient kernel sums over points on the k axis and
 //     cannot un-scale per point), chosen by the caller from the slab's largest |ga| as sampled by a DRY instantiation of this
 //     kernel over every k-th tile group (no stores, atomicMax per slab); fmed3 clamps what a sample might have missed.
+// Residual blocks (HAS_RES; x' = sin(x + W2 sin(W1 x + b1) + b2), siren.py:218-230) are two slabs of the same chain -- fc1 then
+// fc2, both with freq = 1 -- plus the identity path: the output of the slab below the block also feeds fc2's argument directly,
+// so  g_h of that slab = W1^T gp_fc1 + ga_fc2.  ga_fc2 = gp_fc2 is exactly the B operand fc2's epilogue produced (fp16, times
+// that slab's per-point scale T): a copy of those 16 fragments stays in registers across the two products and is added, re-scaled,
+// to the accumulators in the epilogue two slabs further down; the operand bound of that slab grows by the point's max |ga_fc2|.
 // Weight units (two 32-row output tiles of a transposed matrix: 2 * KCH KiB) stream through a three-slot ring in LDS by
 // LDS-DMA, shared by the block's four waves, which work on four tiles of one image in lockstep (one barrier per unit) -- the
 // scheme of field_h3.hip.  cos(arg) is fetched a slab's worth of output tiles ahead of the epilogue that consumes it.
+constexpr int C16_MAX_SLABS = 2 * CNERF_MAX_LAYERS;
+enum { C16_FILM = 0, C16_SINE = 1, C16_RES_FC1 = 2, C16_RES_FC2 = 3 };
 struct Chain16Args {
     FieldArgs f;              // geometry, tiles, freq, flags, layer kinds, gradient volumes, grad_out / saved_out
     const f16x8* units;       // transposed weight units in consumption order (pack_chain16)
@@ -231,6 +238,7 @@ struct Chain16Args {
     unsigned int* gmax;       // dry run: per slab the bits of max |ga| (non-negative floats order like their bits), then max |go'|
     int nslab;
     int group_step;           // process every group_step-th tile group of a block's range (dry-run sampling)
+    unsigned char slab_kind[C16_MAX_SLABS];   // per slab: C16_FILM / C16_SINE / C16_RES_FC1 / C16_RES_FC2
 };
 
 __device__ __forceinline__ float pow2_scale_to_2p14(float bound) {
@@ -250,13 +258,23 @@ struct Epi16 {
     float s4[4];              // the stored quad being assembled
     float gp_even;            // the operand pair being assembled
     bool live;
+    float kskip;              // HAS_RES: identity-path fragments (x T_skip) -> accumulator units; 0: this slab has no identity input
 };
 
+__device__ __forceinline__ float h16_lo(uint32_t u) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(u & 0xffffu)); }
+__device__ __forceinline__ float h16_hi(uint32_t u) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(u >> 16)); }
+
 // one element r of output tile t: acc -> (store, operand fragment)
-template <bool DRY>
-__device__ __forceinline__ void epi16_element(const f32x16& acc, const f16x4* cosq, int t, int h, int r, Epi16& st, u32x4* frag_out) {
+template <bool DRY, bool HAS_RES>
+__device__ __forceinline__ void epi16_element(const f32x16& acc, const f16x4* cosq, int t, int h, int r, Epi16& st, u32x4* frag_out,
+                                              const u32x4* frag_skip) {
     const int gq = r >> 2, e = r & 3;
-    const float ac = acc[r] * (float)cosq[gq][e];
+    float av = acc[r];
+    if (HAS_RES && st.kskip != 0.0f) {       // (wave-uniform) + the identity path of the residual block above
+        const uint32_t w = frag_skip[2 * t + (r >> 3)][(r & 7) >> 1];
+        av = __builtin_fmaf((r & 1) ? h16_hi(w) : h16_lo(w), st.kskip, av);
+    }
+    const float ac = av * (float)cosq[gq][e];
     const float gs = ac * st.US;                                             // ga * S_m
     const float f = st.fr ? st.fr[32 * t + 8 * gq + 4 * h + e] : 1.0f;
     const float gt = (ac * f) * st.UT;                                       // gp * T
@@ -271,7 +289,7 @@ __device__ __forceinline__ void epi16_element(const f32x16& acc, const f16x4* co
     else frag_out[2 * t + (r >> 3)][(r & 7) >> 1] = pk_f16(st.gp_even, gt);
 }
 
-template <int NT, bool DRY>
+template <int NT, bool DRY, bool HAS_RES>
 __global__ __launch_bounds__(256) void chain16_kernel(Chain16Args A) {
     extern __shared__ __attribute__((aligned(16))) char smem_c[];
     const FieldArgs& a = A.f;
@@ -284,7 +302,7 @@ __global__ __launch_bounds__(256) void chain16_kernel(Chain16Args A) {
     f16x8* lds_head = lds_units + 3 * UNIT_FR;                                              // NT * 64 fragments
     float* lds_freq = reinterpret_cast<float*>(lds_head + NT * 64);                        // film_stride floats (image of the block)
     float* lds_fmax = lds_freq + (a.film_stride > 0 ? a.film_stride : 4);                  // per slab: max |freq| of the image (1: sine)
-    float* s_g = lds_fmax + CNERF_MAX_LAYERS;                                              // [4][32][33] scatter transpose
+    float* s_g = lds_fmax + C16_MAX_SLABS;                                              // [4][32][33] scatter transpose
     int* s_base = reinterpret_cast<int*>(s_g + 4 * 32 * 33);                               // [4][32][8]
     float* s_w = reinterpret_cast<float*>(s_base + 4 * 32 * 8);                            // [4][32][8]
 
@@ -340,7 +358,7 @@ __global__ __launch_bounds__(256) void chain16_kernel(Chain16Args A) {
     const float S_go = A.scales[2 * A.nslab], winv_head = A.winv[A.nslab];
     const float* anorm = A.winv + A.nslab + 1;                  // ||W_m||_1 per slab, then the head's
     if (!a.freq) {
-        for (int i = threadIdx.x; i < CNERF_MAX_LAYERS; i += 256) lds_fmax[i] = 1.0f;
+        for (int i = threadIdx.x; i < C16_MAX_SLABS; i += 256) lds_fmax[i] = 1.0f;
         __syncthreads();
     }
 
@@ -358,11 +376,11 @@ __global__ __launch_bounds__(256) void chain16_kernel(Chain16Args A) {
         if (b != staged_b && a.freq) {                                                     // block-uniform: FiLM vectors of the image
             __syncthreads();
             for (int i = threadIdx.x; i < a.film_stride; i += 256) lds_freq[i] = a.freq[(size_t)b * a.film_stride + i];
-            for (int i = threadIdx.x; i < CNERF_MAX_LAYERS; i += 256) lds_fmax[i] = 1.0f;
+            for (int i = threadIdx.x; i < C16_MAX_SLABS; i += 256) lds_fmax[i] = 1.0f;
             __syncthreads();
             int fi = 0;
             for (int m = 0; m < A.nslab; ++m) {
-                if (a.layer_kind[m] != CNERF_LAYER_FILM) continue;
+                if (A.slab_kind[m] != C16_FILM) continue;
                 float v = 0.0f;
                 for (int i = threadIdx.x; i < NT * 32; i += 256) v = fmaxf(v, fabsf(lds_freq[fi * NT * 32 + i]));
 #pragma unroll
@@ -409,16 +427,19 @@ __global__ __launch_bounds__(256) void chain16_kernel(Chain16Args A) {
         }
 
         int film_idx = 0;
-        for (int l = 0; l < A.nslab; ++l) film_idx += (a.layer_kind[l] == CNERF_LAYER_FILM);
+        for (int l = 0; l < A.nslab; ++l) film_idx += (A.slab_kind[l] == C16_FILM);
         // B operands: the one being consumed and the one being produced; copied over after every slab (64 moves: swapping
         // pointers instead sends both arrays to scratch memory -- the register indices must be static)
         u32x4 frag_in[KCH], frag_out[KCH];
+        // HAS_RES: gp (= ga) of the last fc2 slab, its per-point scale and the point's max, for the identity path two slabs below
+        u32x4 frag_skip[HAS_RES ? KCH : 1];
+        float T_skip = 1.0f, skip_max = 0.0f;
 
         // epilogue state of the slab whose g_h is being produced
         Epi16 st;
         st.live = live;
         auto begin_slab = [&](int m, float U, float bound_gp) -> float {          // returns T
-            const bool film = a.layer_kind[m] == CNERF_LAYER_FILM;
+            const bool film = A.slab_kind[m] == C16_FILM;
             if (film) --film_idx;
             st.fr = film ? lds_freq + (size_t)film_idx * (NT * 32) : nullptr;
             const float T = pow2_scale_to_2p14(bound_gp);
@@ -427,7 +448,16 @@ __global__ __launch_bounds__(256) void chain16_kernel(Chain16Args A) {
             st.gdst = A.g16 + (size_t)m * slab16 + row16 + 4 * h;
             st.vmax = 0.0f;
             st.gmax = 0.0f;
+            st.kskip = 0.0f;
             return T;
+        };
+        auto keep_skip = [&](int m, float T_m, float gpmax_m) {                    // after a slab's epilogue: is it the fc2 of a block?
+            if (HAS_RES && A.slab_kind[m] == C16_RES_FC2) {
+#pragma unroll
+                for (int c = 0; c < KCH; ++c) frag_skip[c] = frag_out[c];
+                T_skip = T_m;
+                skip_max = gpmax_m;
+            }
         };
         auto end_slab = [&](int m, float T) -> float {                             // returns the point's max |gp| in true units
             if (DRY) {
@@ -461,16 +491,19 @@ __global__ __launch_bounds__(256) void chain16_kernel(Chain16Args A) {
                 z = __builtin_amdgcn_mfma_f32_32x32x16_f16(aw, __builtin_bit_cast(f16x8, bl), z, 0, 0, 0);
                 z = __builtin_amdgcn_mfma_f32_32x32x16_f16(aw, __builtin_bit_cast(f16x8, bh), z, 0, 0, 0);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) epi16_element<DRY>(z, cosr[t % CD], t, h, r, st, frag_out);
+                for (int r = 0; r < 16; ++r) epi16_element<DRY, HAS_RES>(z, cosr[t % CD], t, h, r, st, frag_out, frag_skip);
                 prefetch_after(m, t);
             }
         }
         float gpmax = end_slab(m, T);
+        keep_skip(m, T, gpmax);
 #pragma unroll
         for (int c = 0; c < KCH; ++c) frag_in[c] = frag_out[c];
         // ---- slabs last-1 .. 0: g_h = W_{m+1}^T gp_{m+1}, epilogue of tile t under the MFMAs of tile t + 1 --------------------
         for (m = A.nslab - 2; m >= 0; --m) {
-            const float Tn = begin_slab(m, A.winv[m + 1] / T, lds_fmax[m] * anorm[m + 1] * gpmax);
+            const bool skip = HAS_RES && m + 2 < A.nslab && A.slab_kind[m + 2] == C16_RES_FC2;      // block-uniform
+            const float Tn = begin_slab(m, A.winv[m + 1] / T, lds_fmax[m] * (anorm[m + 1] * gpmax + (skip ? skip_max : 0.0f)));
+            if (skip) st.kskip = T / (T_skip * A.winv[m + 1]);         // fragment units (x T_skip) -> accumulator units (x T / winv)
             f32x16 acc_prev;
 #pragma unroll
             for (int u = 0; u < NT / 2; ++u) {
@@ -490,7 +523,8 @@ __global__ __launch_bounds__(256) void chain16_kernel(Chain16Args A) {
                         z = __builtin_amdgcn_mfma_f32_32x32x16_f16(aw, __builtin_bit_cast(f16x8, frag_in[c]), z, 0, 0, 0);
                         if (t > 0) {
 #pragma unroll
-                            for (int q = 0; q < EPC; ++q) epi16_element<DRY>(acc_prev, cosr[(t - 1) % CD], t - 1, h, c * EPC + q, st, frag_out);
+                            for (int q = 0; q < EPC; ++q)
+                                epi16_element<DRY, HAS_RES>(acc_prev, cosr[(t - 1) % CD], t - 1, h, c * EPC + q, st, frag_out, frag_skip);
                         }
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                         __builtin_amdgcn_sched_group_barrier(0x002, 9 * EPC, 0);
@@ -501,10 +535,11 @@ __global__ __launch_bounds__(256) void chain16_kernel(Chain16Args A) {
                 }
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) epi16_element<DRY>(acc_prev, cosr[(NT - 1) % CD], NT - 1, h, r, st, frag_out);
+            for (int r = 0; r < 16; ++r) epi16_element<DRY, HAS_RES>(acc_prev, cosr[(NT - 1) % CD], NT - 1, h, r, st, frag_out, frag_skip);
             prefetch_after(m, NT - 1);
             gpmax = end_slab(m, Tn);
             T = Tn;
+            keep_skip(m, T, gpmax);
 #pragma unroll
             for (int c = 0; c < KCH; ++c) frag_in[c] = frag_out[c];
         }
@@ -677,7 +712,26 @@ struct Chain16Launch {
     int nslab, dry, group_step;
 };
 
-template <int NT, bool DRY>
+// slab kinds from the layer kinds: a residual block contributes fc1 and fc2
+static bool slab_kinds_of(const FieldArgs& f, unsigned char* kinds, int nslab) {
+    int m = 0;
+    bool res = false;
+    for (int l = 0; l < f.L; ++l) {
+        if (f.layer_kind[l] == CNERF_LAYER_RES) {
+            if (m + 2 > C16_MAX_SLABS) return false;
+            kinds[m++] = C16_RES_FC1;
+            kinds[m++] = C16_RES_FC2;
+            res = true;
+        } else {
+            if (m + 1 > C16_MAX_SLABS) return false;
+            kinds[m++] = f.layer_kind[l] == CNERF_LAYER_FILM ? C16_FILM : C16_SINE;
+        }
+    }
+    (void)res;
+    return m == nslab;
+}
+
+template <int NT, bool DRY, bool HAS_RES>
 static hipError_t launch_chain16_nt(const FieldArgs& f, const Chain16Launch& c, hipStream_t stream) {
     Chain16Args A;
     A.f = f;
@@ -691,30 +745,38 @@ static hipError_t launch_chain16_nt(const FieldArgs& f, const Chain16Launch& c, 
     A.gmax = c.gmax;
     A.nslab = c.nslab;
     A.group_step = c.group_step < 1 ? 1 : c.group_step;
+    if (!slab_kinds_of(f, A.slab_kind, c.nslab)) return hipErrorInvalidValue;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) != hipSuccess) dev = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
     const size_t lds_bytes = (size_t)3 * (2 * 2 * NT * 64) * 16 + (size_t)NT * 64 * 16 + (size_t)(f.film_stride > 0 ? f.film_stride : 4) * 4 +
-                             (size_t)CNERF_MAX_LAYERS * 4 + (size_t)4 * 32 * 33 * 4 + (size_t)2 * 4 * 32 * 8 * 4;
+                             (size_t)C16_MAX_SLABS * 4 + (size_t)4 * 32 * 33 * 4 + (size_t)2 * 4 * 32 * 8 * 4;
     if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
-    if (hipError_t e = hipFuncSetAttribute((const void*)chain16_kernel<NT, DRY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)) return e;
+    if (hipError_t e = hipFuncSetAttribute((const void*)chain16_kernel<NT, DRY, HAS_RES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)) return e;
     const long long want = (f.total_tiles / f.tiles_per_image) * ((f.tiles_per_image + 3) / 4);
     int blocks = (int)(want < cus ? want : cus);
     if (blocks < 8) blocks = 8;
     blocks = (blocks + 7) / 8 * 8;
-    hipLaunchKernelGGL((chain16_kernel<NT, DRY>), dim3(blocks), dim3(256), lds_bytes, stream, A);
+    hipLaunchKernelGGL((chain16_kernel<NT, DRY, HAS_RES>), dim3(blocks), dim3(256), lds_bytes, stream, A);
     return hipGetLastError();
 }
 
 hipError_t launch_chain16(const FieldArgs& f, int H, const void* units, const void* head_t, const float* winv, const float* scales, const void* cos16,
                           void* g16, void* go16, unsigned int* gmax, int nslab, int dry, int group_step, hipStream_t stream) {
     const Chain16Launch c{units, head_t, winv, scales, cos16, g16, go16, gmax, nslab, dry, group_step};
+    bool res = false;
+    for (int l = 0; l < f.L; ++l) res |= f.layer_kind[l] == CNERF_LAYER_RES;
+#define C16_CASE(NT_)                                                                                                                   \
+    case NT_:                                                                                                                           \
+        if (res) return dry ? launch_chain16_nt<NT_, true, true>(f, c, stream) : launch_chain16_nt<NT_, false, true>(f, c, stream);     \
+        return dry ? launch_chain16_nt<NT_, true, false>(f, c, stream) : launch_chain16_nt<NT_, false, false>(f, c, stream);
     switch (H / 32) {
-        case 2: return dry ? launch_chain16_nt<2, true>(f, c, stream) : launch_chain16_nt<2, false>(f, c, stream);
-        case 4: return dry ? launch_chain16_nt<4, true>(f, c, stream) : launch_chain16_nt<4, false>(f, c, stream);
-        case 8: return dry ? launch_chain16_nt<8, true>(f, c, stream) : launch_chain16_nt<8, false>(f, c, stream);
+        C16_CASE(2)
+        C16_CASE(4)
+        C16_CASE(8)
         default: return hipErrorInvalidValue;
     }
+#undef C16_CASE
 }
 
 }  // namespace cnerf

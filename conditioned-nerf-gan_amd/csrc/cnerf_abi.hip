@@ -670,20 +670,22 @@ struct Chain16Layout {
     int n_mats, n_in, k0, ot0;
 };
 int chain16_layout(const cnerf_cfg* c, Chain16Layout& l) {
-    for (int i = 0; i < c->L; ++i)
-        if (c->layer_kind[i] != CNERF_LAYER_FILM && c->layer_kind[i] != CNERF_LAYER_SINE)
-            return fail(CNERF_ENOSYS, "half-precision backward: FiLM / plain-sine layers only (layer %d is kind %d)", i, c->layer_kind[i]);
+    l.n_mats = 0;
+    for (int i = 0; i < c->L; ++i) {
+        if (c->layer_kind[i] == CNERF_LAYER_PFILM)
+            return fail(CNERF_ENOSYS, "half-precision backward: FiLM / plain-sine / residual layers only (layer %d is per-point FiLM)", i);
+        l.n_mats += c->layer_kind[i] == CNERF_LAYER_RES ? 2 : 1;      // a residual block: fc1 and fc2
+    }
     const size_t NT = c->H / 32, KCH = 2 * NT, frag = 64 * 16;
     const PackedLayout pl = packed_layout(c);
-    l.n_mats = c->L;
     l.n_in = pl.n_in;
     l.k0 = pl.k0;
     l.ot0 = (pl.n_in + 1) / 2 * 2;
-    l.units_bytes = ((size_t)(c->L - 1) * NT + l.ot0) * KCH * frag;
+    l.units_bytes = ((size_t)(l.n_mats - 1) * NT + l.ot0) * KCH * frag;
     l.head_off = align256(l.units_bytes);
     l.winv_off = l.head_off + align256(NT * frag);
-    l.wmax_off = l.winv_off + align256((size_t)2 * (c->L + 1) * sizeof(float));
-    l.total = l.wmax_off + align256((size_t)(c->L + 1) * sizeof(uint32_t));
+    l.wmax_off = l.winv_off + align256((size_t)2 * (l.n_mats + 1) * sizeof(float));
+    l.total = l.wmax_off + align256((size_t)(l.n_mats + 1) * sizeof(uint32_t));
     return CNERF_OK;
 }
 }  // namespace
@@ -710,18 +712,27 @@ int cnerf_pack_field_chain16(const cnerf_cfg* cfg, const cnerf_field_params* p, 
     float* winv = (float*)(base + l.winv_off);
     uint32_t* wmax = (uint32_t*)(base + l.wmax_off);
     char* dst = base;
-    for (int m = cfg->L - 1; m >= 1; --m) {          // consumption order of the chain
-        if (!p->w[m]) return fail(CNERF_EINVAL, "pack_field_chain16: layer %d weight is NULL", m);
-        if (hipError_t e = launch_pack_t16(p->w[m], H, H, H, NT, dst, winv + m, wmax + m, stream)) return hip_fail(e, "pack_t16");
+    const float* mats[2 * CNERF_MAX_LAYERS];         // the matrices in slab order (a residual block: fc1, fc2)
+    int nm = 0;
+    for (int i = 0; i < cfg->L; ++i) {
+        if (!p->w[i]) return fail(CNERF_EINVAL, "pack_field_chain16: layer %d weight is NULL", i);
+        mats[nm++] = p->w[i];
+        if (cfg->layer_kind[i] == CNERF_LAYER_RES) {
+            if (!p->w2[i]) return fail(CNERF_EINVAL, "pack_field_chain16: residual layer %d fc2 is NULL", i);
+            mats[nm++] = p->w2[i];
+        }
+    }
+    const int M = l.n_mats;
+    for (int m = M - 1; m >= 1; --m) {               // consumption order of the chain
+        if (hipError_t e = launch_pack_t16(mats[m], H, H, H, NT, dst, winv + m, wmax + m, stream)) return hip_fail(e, "pack_t16");
         dst += (size_t)NT * KCH * frag;
     }
-    if (!p->w[0]) return fail(CNERF_EINVAL, "pack_field_chain16: layer 0 weight is NULL");
-    if (hipError_t e = launch_pack_t16(p->w[0], H, l.k0, l.k0, l.ot0, dst, winv + 0, wmax + 0, stream)) return hip_fail(e, "pack_t16");
-    if (hipError_t e = launch_pack_head_t16(p->w_final, H, base + l.head_off, winv + cfg->L, wmax + cfg->L, stream)) return hip_fail(e, "pack_head_t16");
-    float* anorm = winv + cfg->L + 1;                  // ||W_m||_1 per matrix, then the head's (4 x H: max over channels of the 4-term sum)
-    for (int m = 0; m < cfg->L; ++m)
-        if (hipError_t e = launch_col_abs_sum_max(p->w[m], H, m == 0 ? l.k0 : H, anorm + m, stream)) return hip_fail(e, "col_abs_sum_max");
-    if (hipError_t e = launch_col_abs_sum_max(p->w_final, 4, H, anorm + cfg->L, stream)) return hip_fail(e, "col_abs_sum_max");
+    if (hipError_t e = launch_pack_t16(mats[0], H, l.k0, l.k0, l.ot0, dst, winv + 0, wmax + 0, stream)) return hip_fail(e, "pack_t16");
+    if (hipError_t e = launch_pack_head_t16(p->w_final, H, base + l.head_off, winv + M, wmax + M, stream)) return hip_fail(e, "pack_head_t16");
+    float* anorm = winv + M + 1;                       // ||W_m||_1 per matrix, then the head's (4 x H: max over channels of the 4-term sum)
+    for (int m = 0; m < M; ++m)
+        if (hipError_t e = launch_col_abs_sum_max(mats[m], H, m == 0 ? l.k0 : H, anorm + m, stream)) return hip_fail(e, "col_abs_sum_max");
+    if (hipError_t e = launch_col_abs_sum_max(p->w_final, 4, H, anorm + M, stream)) return hip_fail(e, "col_abs_sum_max");
     return CNERF_OK;
 }
 

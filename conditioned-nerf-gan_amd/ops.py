@@ -415,13 +415,18 @@ def _pfilm_backward(net, o, cfg, levels, cam2world, rng, saved, gc, gf):
 def backward_precision_of(net):
     """Arithmetic of the backward's gradient GEMMs: `net.backward_precision` = "fp32" (exact fp32 MFMA chain and weight
     gradients, the default) or "fp16" (fp16 operands, fp32 sums: the reference's own training numerics, utils.py:643 autocast);
-    "fp16" covers FiLM / plain-sine networks, the others run the fp32 path."""
+    "fp16" covers FiLM / plain-sine / residual-block networks, the per-point FiLM family runs the fp32 path."""
     p = getattr(net, "backward_precision", "fp32")
     if p not in ("fp32", "fp16"):
         raise L.CnerfError(f"unknown backward precision {p!r}")
-    if p == "fp16" and any(k not in ("film", "sine") for k in net.spec.layers):
+    if p == "fp16" and any(k not in ("film", "sine", "res") for k in net.spec.layers):
         return "fp32"
     return p
+
+
+def n_matrices(net):
+    """Weight matrices before the head ("slabs" of the backward's buffers): a residual block has two."""
+    return sum(2 if k == "res" else 1 for k in net.spec.layers)
 
 
 _pack16_cache = weakref.WeakKeyDictionary()
@@ -462,7 +467,7 @@ def resident_act16(net, levels, B, R, S, hier, dev):
     set per pass: x0, sin, cos), or None when they would not fit the budget -- the backward then re-computes them chunk-wise."""
     H, NT = int(net.hidden_dim), int(net.hidden_dim) // 32
     n_in = sum(int(t.shape[-1]) for t in levels) // 32 + (1 if net.spec.input == "feat_xyz" else 0)
-    nslab = len(net.spec.layers)
+    nslab = n_matrices(net)
     T = B * ((R * R * S + 31) // 32)
     n_pass = 2 if hier else 1
     per_pass = T * 2048 * (n_in + 2 * nslab * NT)
@@ -488,7 +493,9 @@ def _render_backward16(net, o, levels, freq, phase, cam2world, rng, saved, grad_
     H, k0 = int(net.hidden_dim), int(net.input_dim)
     NT = H // 32
     n_in = cfg.C // 32 + (1 if net.spec.input == "feat_xyz" else 0)
-    kinds = net.spec.layers
+    kinds = []                         # one entry per matrix: a residual block contributes fc1 and fc2, both plain-sine slabs
+    for k in net.spec.layers:
+        kinds += ["sine", "sine"] if k == "res" else [k]
     nslab = len(kinds)
     npi = R * R * S
     tpi = (npi + 31) // 32

@@ -319,7 +319,8 @@ int cnerf_weight_grad16(int32_t n_images, int64_t tiles_per_image, int32_t n_row
 
 /* Packed operands of the half-precision gradient chain: every W_l^T (and the head's) as fp16 MFMA fragments, each matrix
  * pre-scaled by a power of two, plus their inverse scales.  Bytes via cnerf_backward16_bytes.  FiLM / plain-sine layers
- * (CNERF_ENOSYS for residual blocks and the per-point FiLM family: use the fp32 backward there). */
+ * (FiLM, plain-sine and residual-block networks; a residual block is two matrices -- fc1, fc2 -- of every per-matrix array below.
+ * CNERF_ENOSYS for the per-point FiLM family: use the fp32 backward there). */
 int cnerf_backward16_bytes(const cnerf_cfg* cfg, size_t* packed16);
 int cnerf_pack_field_chain16(const cnerf_cfg* cfg, const cnerf_field_params* params, void* packed16, void* stream);
 

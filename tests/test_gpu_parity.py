@@ -460,7 +460,8 @@ def test_backward_split_precision(golden, dev, name):
     test_backward_teacher_forced(golden, dev, name, precision="fp16x3")
 
 
-HALF_BACKWARD_FIXTURES = [n for n in GRAD_FIXTURES if n.startswith(("short_fg", "tall_fg", "double_fg", "single_dg", "short_f_", "tall_dgx", "short_pyrmd"))]
+HALF_BACKWARD_FIXTURES = [n for n in GRAD_FIXTURES if n.startswith(("short_fg", "tall_fg", "double_fg", "single_dg", "short_f_", "tall_dgx", "short_pyrmd",
+                                                                     "short_fres", "tall_dres"))]
 
 
 def rel_l2(a, b):
@@ -992,6 +993,15 @@ def test_backward_per_point_film_vs_oracle_autograd(dev, shape):
     _ragged_backward_case(dev, shape, "TALLSIREN", "fp32")
 
 
+@pytest.mark.parametrize("variant", ["TALLSIREN_dRes", "SHORTSIREN_FRes", "TALLSIREN_dResLong"])
+@pytest.mark.parametrize("shape", [dict(B=2, R=5, S=7, V=9, H=64), dict(B=1, R=4, S=33, V=6, H=256)])
+def test_backward_residual_blocks_vs_oracle_autograd(dev, shape, variant):
+    """Residual-block networks (sin(x + W2 sin(W1 x + b1) + b2), siren.py:218-230; two, one and four blocks) through both
+    backward paths against autograd through the CPU oracle: the identity path of the fp32 chain (re-read rows) and of the
+    half-precision chain (operand fragments kept in registers across two products), ragged tiles, narrow and wide."""
+    _ragged_backward_case(dev, shape, variant, ("fp32", "fp16"))
+
+
 def test_benchmarked_shape_backward_vs_oracle_autograd(dev):
     """BASELINE configs 3/4 train at this shape: gradients of one image at 128x128 rays x (64 + 64) samples, 64^3 volume, hidden
     256 (two 32-point tiles per ray, 32 k tiles per pass, the LDS-resident head) against autograd through the CPU oracle on the
@@ -1009,8 +1019,10 @@ def _ragged_backward_case(dev, shape, variant, backward_precisions):
     torch.manual_seed(B * 100 + S)
     np.random.seed(B * 100 + S)
     Z = 32
-    has_glob = variant != "TALLSIREN"
-    gen = ImplicitGenerator3d(variant, Z, 32, 4, H) if has_glob else ImplicitGenerator3d(variant, 32, 3, 4, H)
+    from cnerf_amd.generators.siren import FIELD_SPECS
+    has_glob = variant != "TALLSIREN" and FIELD_SPECS[variant].has_global
+    gen = (ImplicitGenerator3d(variant, Z, 32, 4, H) if has_glob else
+           ImplicitGenerator3d(variant, 32, 3 if variant == "TALLSIREN" else 32, 4, H))
     with torch.no_grad():
         gen.siren.final_layer.weight[3] *= 20
     fvol, glob = torch.randn(B, 32, V, V, V) * 0.5, (torch.randn(B, Z) if has_glob else None)
