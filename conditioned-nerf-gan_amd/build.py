@@ -25,7 +25,8 @@ def build_library(force=False, verbose=False, extra_flags=()):
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     objs, jobs = [], []
     # (source, object, extra defines): field_h3.hip is compiled twice -- fp16x3 split kernel and the single-pass fp16 kernel
-    units = [(src, src.replace(".hip", ".o"), ()) for src in SOURCES] + [("field_h3.hip", "field_h1.o", ("-DCNERF_H3_PARTS=1",))]
+    h1_defs = ("-DCNERF_H3_PARTS=1",) + tuple(os.environ.get("CNERF_H1_FLAGS", "").split())      # (experiments: e.g. -DCNERF_H3_OCC=2)
+    units = [(src, src.replace(".hip", ".o"), ()) for src in SOURCES] + [("field_h3.hip", "field_h1.o", h1_defs)]
     for src, obj, defs in units:
         s = os.path.join(CSRC, src)
         o = os.path.join(CSRC, obj)

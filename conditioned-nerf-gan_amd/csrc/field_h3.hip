@@ -465,8 +465,14 @@ __device__ __forceinline__ TilePoint tile_of_group(const FieldArgs& a, long long
 
 // PAIRED: four LDS slots, one barrier per TWO weight units (single-input networks: the unit's parity inside the tile is then
 // static in the unrolled loops); otherwise two slots and a barrier per unit.
+// Waves per SIMD the kernel is compiled for (register cap 512 / OCC): 1 = one block of four waves per CU.  The single-pass fp16
+// build holds half the operand registers, which is what a second resident block needs (build.py passes -DCNERF_H3_OCC for it).
+#ifndef CNERF_H3_OCC
+#define CNERF_H3_OCC 1
+#endif
+
 template <int NT, int STORE, bool PAIRED, bool HAS_RES>
-__global__ __launch_bounds__(256) void field_h3_kernel(FieldArgs a) {
+__global__ __launch_bounds__(256, CNERF_H3_OCC) void field_h3_kernel(FieldArgs a) {
 #ifdef CNERF_STAMPS
     unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long last_ = __builtin_readcyclecounter();
@@ -796,7 +802,8 @@ static hipError_t launch_h3_inst(const FieldArgs& a, hipStream_t stream) {
     if (lds_bytes > LDS_LIMIT) return hipErrorInvalidValue;
     // (per launch, not once per process: the attribute is per device, and a cached flag would be unsynchronised global state)
     if (hipError_t e = hipFuncSetAttribute((const void*)field_h3_kernel<NT, STORE, PAIRED, HAS_RES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT)) return e;
-    const long long want = (a.total_tiles / a.tiles_per_image) * ((a.tiles_per_image + 3) / 4), cap = (long long)cus;
+    const long long want = (a.total_tiles / a.tiles_per_image) * ((a.tiles_per_image + 3) / 4);
+    const long long cap = (long long)cus * (CNERF_H3_OCC * lds_bytes <= LDS_LIMIT ? CNERF_H3_OCC : 1);
     int blocks = (int)(want < cap ? want : cap);
     if (blocks < 8) blocks = 8;
     blocks = (blocks + 7) / 8 * 8;
