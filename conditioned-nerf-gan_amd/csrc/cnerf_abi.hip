@@ -255,8 +255,9 @@ int cnerf_workspace_bytes(const cnerf_cfg* cfg, size_t* packed, size_t* fvol_cl,
     }
     if (fwd_ws) {
         const size_t N = (size_t)cfg->B * cfg->R * cfg->R * cfg->S;
-        // coarse rgb_sigma + z, fine z + rgb_sigma
-        *fwd_ws = 2 * align256(N * 4 * sizeof(float)) + 2 * align256(N * sizeof(float));
+        // coarse rgb_sigma + z, fine z + rgb_sigma; folded FiLM constants of the call (3 per image, FiLM layer and channel)
+        *fwd_ws = 2 * align256(N * 4 * sizeof(float)) + 2 * align256(N * sizeof(float)) +
+                  align256((size_t)3 * cfg->B * pl.n_film * cfg->H * sizeof(float));
     }
     return CNERF_OK;
 }
@@ -465,7 +466,8 @@ int cnerf_render_forward(const cnerf_cfg* cfg, const cnerf_volumes* vols, const 
     float* c_rs = (float*)ws; ws += align256(N * 4 * sizeof(float));
     float* f_rs = (float*)ws; ws += align256(N * 4 * sizeof(float));
     float* c_z = (float*)ws;  ws += align256(N * sizeof(float));
-    float* f_z = (float*)ws;
+    float* f_z = (float*)ws;  ws += align256(N * sizeof(float));
+    float* fold = (float*)ws;
     if (aux) {   // write straight into the caller's buffers where given
         if (aux->coarse_rgb_sigma) c_rs = aux->coarse_rgb_sigma;
         if (aux->fine_rgb_sigma) f_rs = aux->fine_rgb_sigma;
@@ -477,6 +479,12 @@ int cnerf_render_forward(const cnerf_cfg* cfg, const cnerf_volumes* vols, const 
     if (int rc = fill_field_args(fa, cfg, vols, nullptr, packed, freq, phase)) return rc;
     set_points(fa, cfg->B, npi);
     fa.cam2world = cam2world;
+    // all-FiLM network in the exact fp32 precision: FiLM folded into one affine map per channel, prepared once for both passes
+    if (cfg->precision == CNERF_PREC_FP32 && pl.n_film == cfg->L && cfg->drop_p == 0.0f) {
+        if (hipError_t e = launch_fold_film(freq, phase, (long long)cfg->B * pl.n_film * cfg->H, fold, stream)) return hip_fail(e, "fold_film");
+        fa.fold = fold;
+        fa.fold_images = cfg->B;
+    }
     // 1. coarse pass
     fa.mode = FIELD_MODE_COARSE;
     fa.u_strat = rng->u_strat;

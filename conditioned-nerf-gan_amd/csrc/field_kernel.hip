@@ -86,6 +86,20 @@ constexpr int RING = CNERF_RING;
 // epilogue kinds
 enum { EPI_FILM = 0, EPI_FILM_RES = 1 };
 
+// FOLD (all-FiLM networks, plain forward): arg = freq * pre + phase is affine in the accumulator (which already holds the bias)
+// and v_sin_f32 takes revolutions, so with the per-image constants M = freq / 2 pi = Mh + Ml and K = phase / 2 pi
+// (fold_film_kernel, once per call) the activation is  n = rint(pre Mh);  u = fma(pre, Ml, fma(pre, Mh, -n)) + K;  sin(2 pi u):
+// 5 vector ops + v_sin instead of 2 + the 12-op reduce-and-polynomial sine.  pre * Mh - n is a single-rounding fma of
+// magnitude <= 1/2: the argument never exists rounded at its full magnitude (~200 rad, ulp 1.5e-5), which more than pays
+// for v_sin's 3.8e-7 against the polynomial's 1.2e-7 (the reason the hardware sine alone was rejected above).
+#ifndef CNERF_F32_FOLD
+#define CNERF_F32_FOLD 1
+#endif
+__device__ __forceinline__ float folded_sine(float pre, float mh, float ml, float k) {
+    const float n = __builtin_rintf(pre * mh);
+    return __builtin_amdgcn_sinf(__builtin_fmaf(pre, ml, __builtin_fmaf(pre, mh, -n)) + k);
+}
+
 template <int EPI, bool STORE>
 __device__ __forceinline__ float epilogue_one(float acc, float res, float fr, float ph, float& cs) {
     float pre = acc;
@@ -121,12 +135,13 @@ __device__ __forceinline__ void store_tile_rows(float* __restrict__ row /* &buf[
 // full 2 cycles whether spread between the MFMAs or clumped, with one or two accumulator chains -- so for the fp32
 // path  time = MFMA + VALU + stalls  and the epilogue placement only matters for register pressure and load distance.
 // DROP: the finished tile (and its cosine row) is multiplied by the dropout factors of layer `drop_d` at point `drop_gp`.
-template <int OT, int KT, int EPI, bool STORE, bool DROP = false>
+template <int OT, int KT, int EPI, bool STORE, bool DROP = false, bool FOLD = false>
 __device__ __forceinline__ void mlp_matrix(const f32x4* __restrict__ wp, const float* __restrict__ bias,
                                            const float* __restrict__ freq, const float* __restrict__ phase,
                                            const f32x16* in, const f32x16* res, f32x16* out, int lane, int h,
                                            float* __restrict__ row_h, float* __restrict__ row_c,
-                                           const FieldArgs* da = nullptr, unsigned long long drop_gp = 0, int drop_d = 0) {
+                                           const FieldArgs* da = nullptr, unsigned long long drop_gp = 0, int drop_d = 0,
+                                           const float* __restrict__ fold_ml = nullptr) {     // FOLD: freq = Mh, phase = K
     constexpr int GPT = KT * 4;                       // groups (of 4 MFMAs) per output tile
     constexpr int NG = OT * GPT;
     constexpr int EPG = GPT >= 16 ? 1 : 16 / GPT;     // epilogue elements handled per group
@@ -135,7 +150,7 @@ __device__ __forceinline__ void mlp_matrix(const f32x4* __restrict__ wp, const f
 #pragma unroll
     for (int i = 0; i < RING; ++i)
         if (i < NG) ring[i] = wp[i * 64 + lane];
-    f32x16 acc_prev, fr_prev, ph_prev, cos_t;
+    f32x16 acc_prev, fr_prev, ph_prev, ml_prev, cos_t;
     f32x16 bias_next = load_chan16(bias, 0, h);       // per-channel vectors are fetched one output tile ahead
 #pragma unroll
     for (int t = 0; t < OT; ++t) {
@@ -143,6 +158,8 @@ __device__ __forceinline__ void mlp_matrix(const f32x4* __restrict__ wp, const f
         if (t + 1 < OT) bias_next = load_chan16(bias, t + 1, h);
         const f32x16 fr = load_chan16(freq, t, h);
         const f32x16 ph = load_chan16(phase, t, h);
+        f32x16 ml;
+        if (FOLD) ml = load_chan16(fold_ml, t, h);
 #pragma unroll
         for (int gi = 0; gi < GPT; ++gi) {
             const int tk = gi >> 2, g = gi & 3;
@@ -157,8 +174,9 @@ __device__ __forceinline__ void mlp_matrix(const f32x4* __restrict__ wp, const f
                 for (int q = 0; q < EPG; ++q) {
                     const int r = (gi / ESTEP) * EPG + q;
                     float cs_ = 0.0f;
-                    out[t - 1][r] = epilogue_one<EPI, STORE>(acc_prev[r], EPI == EPI_FILM_RES ? res[t - 1][r] : 0.0f, fr_prev[r],
-                                                             ph_prev[r], cs_);
+                    if (FOLD) out[t - 1][r] = folded_sine(acc_prev[r], fr_prev[r], ml_prev[r], ph_prev[r]);
+                    else out[t - 1][r] = epilogue_one<EPI, STORE>(acc_prev[r], EPI == EPI_FILM_RES ? res[t - 1][r] : 0.0f, fr_prev[r],
+                                                                  ph_prev[r], cs_);
                     if (STORE) cos_t[r] = cs_;
                 }
             }
@@ -175,12 +193,14 @@ __device__ __forceinline__ void mlp_matrix(const f32x4* __restrict__ wp, const f
         acc_prev = acc;
         fr_prev = fr;
         ph_prev = ph;
+        if (FOLD) ml_prev = ml;
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         float cs_ = 0.0f;
-        out[OT - 1][r] = epilogue_one<EPI, STORE>(acc_prev[r], EPI == EPI_FILM_RES ? res[OT - 1][r] : 0.0f, fr_prev[r], ph_prev[r],
-                                                  cs_);
+        if (FOLD) out[OT - 1][r] = folded_sine(acc_prev[r], fr_prev[r], ml_prev[r], ph_prev[r]);
+        else out[OT - 1][r] = epilogue_one<EPI, STORE>(acc_prev[r], EPI == EPI_FILM_RES ? res[OT - 1][r] : 0.0f, fr_prev[r], ph_prev[r],
+                                                       cs_);
         if (STORE) cos_t[r] = cs_;
     }
     if (DROP) {
@@ -216,10 +236,11 @@ __device__ __forceinline__ void layer0_accumulate(const f32x4* __restrict__ wp, 
 }
 
 // x[t] = sin(freq * y[t] + phase) for all tiles (+ activation store)
-template <int NT, bool STORE, bool DROP = false>
+template <int NT, bool STORE, bool DROP = false, bool FOLD = false>
 __device__ __forceinline__ void film_all(const f32x16* y, f32x16* x, const float* __restrict__ freq,
                                          const float* __restrict__ phase, int h, float* row_h, float* row_c,
-                                         const FieldArgs* da = nullptr, unsigned long long drop_gp = 0) {
+                                         const FieldArgs* da = nullptr, unsigned long long drop_gp = 0,
+                                         const float* __restrict__ fold_ml = nullptr) {
     f32x16 fr_n = load_chan16(freq, 0, h), ph_n = load_chan16(phase, 0, h);      // per-channel vectors one tile ahead of their use
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -233,11 +254,17 @@ __device__ __forceinline__ void film_all(const f32x16* y, f32x16* x, const float
         const f32x16 fr = t == 0 ? fr_n : load_chan16(freq, t, h), ph = t == 0 ? ph_n : load_chan16(phase, t, h);
 #endif
         f32x16 o, cs;
+        if (FOLD) {
+            const f32x16 ml = load_chan16(fold_ml, t, h);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[r] = folded_sine(y[t][r], fr[r], ml[r], ph[r]);
+        } else {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             float c_ = 0.0f;
             o[r] = epilogue_one<EPI_FILM, STORE>(y[t][r], 0.0f, fr[r], ph[r], c_);
             if (STORE) cs[r] = c_;
+        }
         }
         if (DROP) {
             if (STORE) drop_tile2(*da, drop_gp, 0, NT * 32, t, h, o, cs);
@@ -280,7 +307,7 @@ __device__ __forceinline__ void film_all(const f32x16* y, f32x16* x, const float
 #define CNERF_F32_LOOKUP_DMA 0
 #endif
 
-template <int NT, bool HAS_RES, bool STORE, bool DROP>
+template <int NT, bool HAS_RES, bool STORE, bool DROP, bool FOLD = false>
 __global__ __launch_bounds__(256) void field_tile_kernel(FieldArgs a) {
 #ifdef CNERF_STAMPS
     unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -347,8 +374,12 @@ __global__ __launch_bounds__(256) void field_tile_kernel(FieldArgs a) {
         const float* bias = a.bias;              // concatenated biases, layer after layer (H each, RES: 2H)
         const float* ones = a.bias + a.bias_floats;
         const float* zeros = ones + H;
-        const float* freq = a.freq ? a.freq + (size_t)b * a.film_stride : nullptr;
-        const float* phase = a.phase ? a.phase + (size_t)b * a.film_stride : nullptr;
+        // FOLD: `freq` / `phase` walk the folded constants Mh / K of the image instead, `fml` the low parts Ml (a.fold: three
+        // arrays of (B, film_stride) floats: Mh, Ml, K)
+        const size_t fold_n = FOLD ? (size_t)a.fold_images * a.film_stride : 0;
+        const float* freq = FOLD ? a.fold + (size_t)(b + a.image0) * a.film_stride : (a.freq ? a.freq + (size_t)b * a.film_stride : nullptr);
+        const float* phase = FOLD ? freq + 2 * fold_n : (a.phase ? a.phase + (size_t)b * a.film_stride : nullptr);
+        const float* fml = FOLD ? freq + fold_n : nullptr;
 #pragma unroll
         for (int t = 0; t < NT; ++t) y.v[t] = load_chan16(bias, t, h);
         for (int tk = 0; tk < a.n_in; ++tk) {
@@ -368,7 +399,7 @@ __global__ __launch_bounds__(256) void field_tile_kernel(FieldArgs a) {
         STAMP(1);   // position + lookups + layer-0 products
         {
             const bool film = a.layer_kind[0] == CNERF_LAYER_FILM;
-            film_all<NT, STORE, DROP>(y.v, x.v, film ? freq : ones, film ? phase : zeros, h, row_h, row_c, &a, drop_gp);
+            film_all<NT, STORE, DROP, FOLD>(y.v, x.v, film ? freq : ones, film ? phase : zeros, h, row_h, row_c, &a, drop_gp, fml);
             if (STORE) {
                 row_h += act_layer;
                 row_c += act_layer;
@@ -378,6 +409,7 @@ __global__ __launch_bounds__(256) void field_tile_kernel(FieldArgs a) {
             if (film) {
                 freq += H;
                 phase += H;
+                if (FOLD) fml += H;
             }
         }
         asm volatile("" :: "v"(x.v[0][0]), "v"(x.v[NT - 1][15]));
@@ -387,8 +419,8 @@ __global__ __launch_bounds__(256) void field_tile_kernel(FieldArgs a) {
             if (!HAS_RES || kind != CNERF_LAYER_RES) {
                 const bool film = kind == CNERF_LAYER_FILM;
                 ++drop_d;
-                mlp_matrix<NT, NT, EPI_FILM, STORE, DROP>(wp, bias, film ? freq : ones, film ? phase : zeros, x.v, nullptr, y.v, lane,
-                                                          h, row_h, row_c, &a, drop_gp, drop_d);
+                mlp_matrix<NT, NT, EPI_FILM, STORE, DROP, FOLD>(wp, bias, film ? freq : ones, film ? phase : zeros, x.v, nullptr, y.v, lane,
+                                                                h, row_h, row_c, &a, drop_gp, drop_d, fml);
                 if (STORE) {
                     row_h += act_layer;
                     row_c += act_layer;
@@ -398,6 +430,7 @@ __global__ __launch_bounds__(256) void field_tile_kernel(FieldArgs a) {
                 if (film) {
                     freq += H;
                     phase += H;
+                    if (FOLD) fml += H;
                 }
 #pragma unroll
                 for (int t = 0; t < NT; ++t) x.v[t] = y.v[t];
@@ -946,6 +979,23 @@ hipError_t launch_fill(float* dst, float value, int n, hipStream_t stream) {
     return hipGetLastError();
 }
 
+// folded FiLM constants of a call (see folded_sine): out = [Mh | Ml | K], n = B * film_stride floats each
+__global__ void fold_film_kernel(const float* __restrict__ freq, const float* __restrict__ phase, long long n, float* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const double M = (double)freq[i] * 0.15915494309189533577;
+        const float mh = (float)M;
+        out[i] = mh;
+        out[n + i] = (float)(M - (double)mh);
+        out[2 * n + i] = (float)((double)phase[i] * 0.15915494309189533577);
+    }
+}
+
+hipError_t launch_fold_film(const float* freq, const float* phase, long long n, float* out, hipStream_t stream) {
+    hipLaunchKernelGGL(fold_film_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, freq, phase, n, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_pack_matrix(const float* w, int n_out, int K_real, int OT, float* dst, hipStream_t stream) {
     const int K = (K_real + 31) / 32 * 32;
     const int total = OT * (K / 32) * 4 * 64 * 4;
@@ -1013,16 +1063,16 @@ hipError_t launch_field_backward(const FieldArgs& a, int H, hipStream_t stream) 
     }
 }
 
-template <int NT, bool HAS_RES, bool STORE, bool DROP>
+template <int NT, bool HAS_RES, bool STORE, bool DROP, bool FOLD = false>
 static hipError_t launch_field_tile(const FieldArgs& a, hipStream_t stream) {
     if (a.n_in < 1 || a.in_level[0] < 0) return hipErrorInvalidValue;      // the lookup prefetch assumes a volume tile first
-    const void* fn = (const void*)field_tile_kernel<NT, HAS_RES, STORE, DROP>;
+    const void* fn = (const void*)field_tile_kernel<NT, HAS_RES, STORE, DROP, FOLD>;
     const int lds_bytes = (CNERF_F32_LOOKUP_DMA && NT >= 4) ? 4 * 32 * 1024 : 0;   // lookup staging of the four waves
     // (per launch, not once per process: the attribute is per device, and a cached flag would be unsynchronised global state)
     if (lds_bytes)
         if (hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)) return e;
     const int blocks = lds_bytes ? field_grid_one_per_cu(a.total_tiles) : field_grid(fn, a.total_tiles);
-    hipLaunchKernelGGL((field_tile_kernel<NT, HAS_RES, STORE, DROP>), dim3(blocks), dim3(256), lds_bytes, stream, a);
+    hipLaunchKernelGGL((field_tile_kernel<NT, HAS_RES, STORE, DROP, FOLD>), dim3(blocks), dim3(256), lds_bytes, stream, a);
     return hipGetLastError();
 }
 
@@ -1031,6 +1081,7 @@ static hipError_t launch_field_nt(const FieldArgs& a, hipStream_t stream) {
     // a.act_h set: activation-storing forward of the backward pass; a.drop_scale != 0: dropout (training mode)
     if (a.drop_scale != 0.0f)
         return a.act_h ? launch_field_tile<NT, HAS_RES, true, true>(a, stream) : launch_field_tile<NT, HAS_RES, false, true>(a, stream);
+    if (CNERF_F32_FOLD && !HAS_RES && a.fold && !a.act_h) return launch_field_tile<NT, false, false, false, true>(a, stream);
     return a.act_h ? launch_field_tile<NT, HAS_RES, true, false>(a, stream) : launch_field_tile<NT, HAS_RES, false, false>(a, stream);
 }
 
