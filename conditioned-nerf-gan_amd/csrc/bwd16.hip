@@ -581,16 +581,23 @@ __global__ __launch_bounds__(256) void chain16_kernel(Chain16Args A) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 float* gv = a.lvl_grad[lvl] + (size_t)b * V * V * V * C + a.in_chan[tk];
+                // Two points per wave instruction, 32 channels each.  The eight corner weights / voxel indices of a point are two
+                // 16-byte LDS reads each (the half-wave reads one address: a broadcast), fetched for the whole iteration up front
+                // and unconditionally added -- a zero weight (clamped border corner, padded lane) adds 0.0 to a valid voxel;
+                // one LDS round trip per pair of points instead of sixteen dependent ones behind eight branches.
+#pragma unroll 2
                 for (int pp = 0; pp < 16; ++pp) {
-                    const int p = 2 * pp + h;                  // two points per wave instruction, 32 channels each
+                    const int p = 2 * pp + h;
                     const float gval = sg[p * 33 + ch];
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        const float wk = sw[p * 8 + k];
+                    const f32x4 w0 = *reinterpret_cast<const f32x4*>(sw + p * 8), w1 = *reinterpret_cast<const f32x4*>(sw + p * 8 + 4);
+                    const u32x4 b0 = *reinterpret_cast<const u32x4*>(sb + p * 8), b1 = *reinterpret_cast<const u32x4*>(sb + p * 8 + 4);
 #ifndef C16_NOSCATTER
-                        if (wk != 0.0f) atomicAdd(gv + (size_t)sb[p * 8 + k] * C + ch, gval * wk);
-#endif
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        atomicAdd(gv + (size_t)b0[k] * C + ch, gval * w0[k]);
+                        atomicAdd(gv + (size_t)b1[k] * C + ch, gval * w1[k]);
                     }
+#endif
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
