@@ -1241,3 +1241,34 @@ def test_dropout_in_kernel_decisions_equal_their_numpy_twin(golden, dev, name):
         px2, _ = gen(z, G(g["cam2worlds"], dev), m["R"], m["fov"], m["ray_start"], m["ray_end"], m["S"], m["hierarchical"], clamp_mode=m["clamp"],
                      nerf_noise=m["noise"], white_back=m["white_back"], last_back=m["last_back"], _rng=dict(base, drop=(p, (seed, offset + 1))))
     assert not torch.equal(px2, runs[0][0])
+
+
+def test_dropout_decisions_do_not_depend_on_the_chunking(dev, golden):
+    """The backward re-runs the forward per chunk of images (ops.ACT_BUDGET_BYTES); keep decisions are indexed by the point's position
+    in the WHOLE call (image0 offsets of the Philox counter and of the injected bytes), so one image per chunk must give the
+    gradients of all images in one chunk -- in-kernel draws and injected bytes alike."""
+    import cnerf_amd
+    from cnerf_amd import ops
+    g = golden("short_fg_drop_small")
+    m = g.meta
+    assert m["B"] == 2
+    gen = make_generator(g, dev)
+    gen.train()
+    base = {k: v for k, v in _dropout_rng(g, dev).items() if not k.startswith("drop_")}
+    for rng in (dict(base, drop=(m["drop_out"], (99, 3))), _dropout_rng(g, dev)):
+        res = []
+        budget = ops.ACT_BUDGET_BYTES
+        try:
+            for b in (budget, 1):                      # 1 byte: one image per chunk
+                ops.ACT_BUDGET_BYTES = b
+                z, vleaves, glob = make_z(g, dev, requires_grad=True)
+                gen.zero_grad()
+                px, dp = gen(z, G(g["cam2worlds"], dev), m["R"], m["fov"], m["ray_start"], m["ray_end"], m["S"], True, clamp_mode=m["clamp"],
+                             nerf_noise=m["noise"], white_back=m["white_back"], last_back=m["last_back"], _rng=dict(rng))
+                (px.square().mean() + dp.mean()).backward()
+                res.append({"feature_volume": vleaves[0].grad.clone(), "global": glob.grad.clone(),
+                            **{k: q.grad.clone() for k, q in gen.named_parameters()}})
+        finally:
+            ops.ACT_BUDGET_BYTES = budget
+        for k in res[0]:
+            assert scaled_err(res[1][k].cpu().numpy(), res[0][k].cpu().numpy()) < 1e-5, k
