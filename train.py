@@ -35,6 +35,11 @@ def main():
                     help="gradient GEMMs of the render backward: exact fp32 MFMA, or fp16 operands with fp32 sums")
     ap.add_argument("--encoder-autocast", default=None, choices=["bf16", "fp16"],
                     help="run the 3D U-Net's convolutions under torch.autocast (the reference trains under fp16 autocast)")
+    ap.add_argument("--teacher", action="store_true",
+                    help="a learnable synthetic task: the target images are renders of the batch's voxel grids by a frozen, differently "
+                         "initialised encoder + generator (default: random images, which nothing can fit)")
+    ap.add_argument("--no-discriminator", action="store_true", help="photometric loss only (no D step, no adversarial term)")
+    ap.add_argument("--lr-scale", type=float, default=1.0, help="multiplies the three learning rates of the default config")
     ap.add_argument("--no-miopen-find", action="store_true",
                     help="keep MIOpen's immediate-mode kernel choice for the Conv3d/Conv2d layers (fast start, 3x slower steps)")
     ap.add_argument("--checkpoint-dir", default=None, help="write <step>.tar (the reference's checkpoint keys) after the last step")
@@ -64,6 +69,9 @@ def main():
     md["render_precision"] = args.precision
     md["backward_precision"] = args.backward_precision
     md["encoder_autocast"] = args.encoder_autocast
+    md["enable_discriminator"] = not args.no_discriminator
+    for k in ("gen_lr", "disc_lr", "enc_lr"):
+        md[k] *= args.lr_scale
     md["miopen_find"] = not args.no_miopen_find
     md["encoder_channels_last"] = bool(int(os.environ.get("CNERF_ENCODER_CHANNELS_LAST", "0")))
     trainer = GanTrainer(md, dev, ddp=world > 1)
@@ -73,6 +81,28 @@ def main():
         if rank == 0:
             print(f"resumed from {args.resume} at step {ck['step']}", flush=True)
     gen = torch.Generator().manual_seed(1000 + rank)
+    teacher = None
+    if args.teacher:
+        from cnerf_amd.generators import ImplicitGenerator3d
+        from cnerf_amd.training.encoder import UNet3D
+        torch.manual_seed(4321)                       # the same teacher on every rank
+        t_enc = UNet3D(**md["unet"]).to(dev).eval()
+        t_gen = ImplicitGenerator3d(**md["generator"]).to(dev).eval()
+        t_gen.set_device(dev)
+        t_gen.siren.precision = args.precision
+        with torch.no_grad():                         # default-init heads render empty space: give the teacher colours and densities
+            t_gen.siren.final_layer.weight[:3] *= 6.0
+            t_gen.siren.final_layer.weight[3] *= 40.0
+            t_gen.siren.final_layer.bias[3] += 0.25
+        torch.manual_seed(rank)
+
+        def teacher(sample):
+            with torch.no_grad():
+                imgs = []
+                for c in trainer._chunks(sample["voxel"].shape[0]):
+                    imgs.append(t_gen(t_enc(sample["voxel"][c]), sample["cam2world"][c], **{**md, "nerf_noise": 0.0})[0])
+                sample["img"] = torch.cat(imgs, 0)
+            return sample
     import threading
     first_done = threading.Event()
 
@@ -100,6 +130,8 @@ def main():
             dist.barrier()
     for step in range(args.steps):
         sample = synthetic_sample(args.batch, args.img_size, args.voxel_res, dev, gen)
+        if teacher is not None:
+            sample = teacher(sample)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         trainer.step(sample)
@@ -107,7 +139,8 @@ def main():
         dt = time.perf_counter() - t0
         first_done.set()
         if rank == 0 and step % args.print_freq == 0:
-            print(f"step {step}: D {trainer.losses['d'][-1]:.4f}  G {trainer.losses['g'][-1]:.4f}  photo {trainer.losses['photo'][-1]:.4f}  "
+            d_loss = trainer.losses["d"][-1] if trainer.losses["d"] else float("nan")        # (no D step without a discriminator)
+            print(f"step {step}: D {d_loss:.4f}  G {trainer.losses['g'][-1]:.4f}  photo {trainer.losses['photo'][-1]:.4f}  "
                   f"alpha {trainer.alpha:.3f}  nerf_noise {md['nerf_noise']:.3f}  sec/step {dt:.3f}  "
                   f"({world * args.batch * args.img_size ** 2 * 2 / dt / 1e6:.2f} M rays/s rendered, D + G passes)", flush=True)
     if args.checkpoint_dir and rank == 0:
