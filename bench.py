@@ -538,7 +538,7 @@ def main():
         roof = {"kernel": "field_h3_kernel<8> (sample + trilinear lookup + FiLM-SIREN MLP, fp16x3 split, fp32 accumulate)",
                 "bound": "mfma", "achieved": 3 * achieved, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": 3 * achieved / PEAK_F16_MFMA_TFLOPS, "traffic": None, "algorithmic_tflops": achieved}
-        pk = pmc_bytes("void cnerf::field_h3_kernel")
+        pk = pmc_bytes("void cnerf::h3::field_h3_kernel")
     else:
         roof = {"kernel": "field_tile_kernel<8> (sample + trilinear lookup + FiLM-SIREN MLP, fp32 MFMA)",
                 "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",

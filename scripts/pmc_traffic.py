@@ -11,7 +11,7 @@ import json
 import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-POINTS = {"void cnerf::field_tile_kernel": 2 * 128 * 128 * 64, "void cnerf::field_h3_kernel": 2 * 128 * 128 * 64,
+POINTS = {"void cnerf::field_tile_kernel": 2 * 128 * 128 * 64, "void cnerf::h3::field_h3_kernel": 2 * 128 * 128 * 64,
           "cnerf::gather_kernel": 2 * 2 * 128 * 128 * 64, "cnerf::composite_kernel": 2 * 2 * 128 * 128 * 64,
           "cnerf::resample_kernel": 2 * 128 * 128 * 64, "cnerf::merge_composite_kernel": 2 * 2 * 128 * 128 * 64}
 
@@ -38,9 +38,9 @@ def main():
                 continue
             if prec == "unfused" and key not in ("cnerf::gather_kernel", "cnerf::composite_kernel"):
                 continue                      # (that run's forward writes its sample points: not the benchmarked forward)
-            if prec != "unfused" and key.startswith("void cnerf::field") and ((prec == "fp32") != ("field_tile" in key)):
+            if prec != "unfused" and "::field_" in key and ((prec == "fp32") != ("field_tile" in key)):
                 continue
-            if prec == "fp16x3" and not key.startswith("void cnerf::field"):
+            if prec == "fp16x3" and "::field_" not in key:
                 continue                      # the per-ray kernels do not depend on the precision: keep one copy
             write = tabs["WRITE_SIZE"][name]
             hbm = (2 * fetch + write) * 1024.0
