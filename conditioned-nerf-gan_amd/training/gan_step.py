@@ -1,6 +1,7 @@
 """One GAN step around the HIP generator (counterpart of Trainer.train_discriminator / train_generator / set_alpha,
-utils.py:610-842 of the reference, which is not importable: F4 of SURVEY.md).  fp32 throughout (the reference's CUDA AMP
-has no place here: the render path is fp32 by contract), Adam(beta = (0, 0.9)), non-saturating logistic losses
+utils.py:610-842 of the reference, which is not importable: F4 of SURVEY.md).  fp32 by default; where the reference wraps
+the step in CUDA AMP (utils.py:327,643) this harness has explicit switches instead -- metadata["render_precision"] /
+["backward_precision"] for the render path, ["encoder_autocast"] for the U-Net.  Adam(beta = (0, 0.9)), non-saturating logistic losses
 softplus(+-pred), R1 penalty on real images, gradient clipping, `batch_split` gradient accumulation.  Under
 torch.distributed every rank trains on its own images; DDP (backend "nccl" = RCCL over xGMI) averages the gradients, and
 all but the last accumulation chunk run under no_sync() so there is one all-reduce per optimizer step (the reference
@@ -198,16 +199,17 @@ class GanTrainer:
         the encoder runs ONCE per accumulation chunk, with its autograd graph, before the D step: the D step's no-grad renders
         read that output, the G step back-propagates through it.  Same numbers as the reference's recomputation
         (utils.py:653-657,778-781), one encoder forward per chunk less (64 ms of a 307 ms step at 128x128x64, batch 8).  Under
-        DDP the last chunk is left out: its forward must be the one directly followed by the backward that all-reduces."""
+        DDP the last of several chunks is left out: its forward must be the one directly followed by the backward that all-reduces."""
         self.set_alpha()
         self._z = {}
         if self.metadata["enable_discriminator"] and self.metadata.get("reuse_encoder_output", True):
             voxels = sample["voxel"].to(self.device)
             chunks = self._chunks(voxels.shape[0])
             for i, c in enumerate(chunks):
-                if self.ddp and i == len(chunks) - 1:
-                    continue
-                with (self.encoder_ddp.no_sync() if self.ddp else contextlib.nullcontext()):
+                last = i == len(chunks) - 1
+                if self.ddp and last and len(chunks) > 1:
+                    continue                 # (a single chunk is fine: no other encoder backward sits between its forward and its own)
+                with (self.encoder_ddp.no_sync() if self.ddp and not last else contextlib.nullcontext()):
                     self._z[i] = self._encode(voxels[c])
         if self.metadata["enable_discriminator"]:
             self.train_discriminator(sample)

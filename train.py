@@ -26,7 +26,9 @@ def main():
     ap.add_argument("--img-size", type=int, default=128)
     ap.add_argument("--num-steps", type=int, default=64)
     ap.add_argument("--batch", type=int, default=8, help="images per GPU per step")
-    ap.add_argument("--batch-split", type=int, default=4)
+    ap.add_argument("--batch-split", type=int, default=1,
+                    help="gradient-accumulation chunks per step; the reference's configs use 4-6 to fit 48 GB GPUs, 288 GB of HBM take the "
+                         "whole batch at once (0.218 s/step against 0.267 with 4 chunks at batch 8)")
     ap.add_argument("--voxel-res", type=int, default=64)
     ap.add_argument("--siren-type", default="SHORTSIREN_FG")
     ap.add_argument("--hidden", type=int, default=256)
