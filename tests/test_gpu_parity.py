@@ -717,6 +717,15 @@ def test_benchmarked_shape_matches_oracle(dev):
     print("benchmarked shape:", res)
 
 
+def test_config5_shape_matches_oracle(dev):
+    """BASELINE config 5's shape: 256x256 rays x (96 + 96) samples (three 32-point tiles per ray, 12.6 M field evaluations per
+    image), 64^3 volume, hidden 256, one image, against the CPU oracle on identical inputs and draws -- the exact fp32 kernel and
+    the fp16x3 split at the 1e-4 gate (the single-pass fp16 arithmetic that config names is covered, at its own tolerance, by
+    test_single_pass_fp16 and at this size by test_full_size_properties)."""
+    res = _oracle_case(dev, "SHORTSIREN_FG", B=1, R=256, S=96, V=64, H=256, Z=256, precision=("fp32", "fp16x3"), seed=13)
+    print("config-5 shape:", res)
+
+
 def test_config2_shape_matches_oracle(dev):
     """BASELINE config 2 as it is written: 64x64 rays x 24 samples, 64^3 volume, hidden 256, one image (the `short_fg_64x24`
     fixture of the reference uses a 24^3 volume to stay small)."""
