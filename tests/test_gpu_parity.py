@@ -1327,3 +1327,48 @@ def test_paired_waves_variant_of_the_split_kernel(golden, dev, precision):
                 gen((fv, gl), cam, 7, 49.13, 0.25, 1.95, 11, True, clamp_mode="relu", nerf_noise=0.0, _rng=rng, _aux=aux)
             res.append(aux["coarse_rgb_sigma"])
         assert rgb_sigma_err(res[1], res[0]) < (2e-5 if precision == "fp16x3" else 2e-2), H
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fp16x3"])
+def test_forward_replays_from_a_hip_graph(dev, precision):
+    """Every launch of a forward (folded-FiLM preparation, the two field passes, resampling, merge; in-kernel Philox draws: no RNG
+    kernels) goes to the current stream through the C ABI, so torch's stream capture records it as it is: the hipGraph replay
+    reproduces the eager image bit for bit, and after the inputs are overwritten in place it renders the new inputs (small renders
+    are launch-bound: scripts/graph_replay.py times eager against replay)."""
+    import cnerf_amd
+    from cnerf_amd.generators import ImplicitGenerator3d
+    torch.manual_seed(21)
+    B, R, S, V = 2, 16, 12, 16
+    gen = ImplicitGenerator3d("SHORTSIREN_FG", 64, 32, 4, 128).to(dev)
+    gen.set_device(dev)
+    gen.eval()
+    gen.siren.precision = precision
+    fvol, glob = torch.randn(B, 32, V, V, V, device=dev) * 0.5, torch.randn(B, 64, device=dev)
+    cam = torch.eye(4, device=dev).unsqueeze(0).repeat(B, 1, 1).contiguous()
+    cam[:, 2, 3] = -1.0
+    rng = {"philox": (1234, 5)}
+
+    def call():
+        with torch.no_grad():
+            return gen((fvol, glob), cam, R, 49.13, 0.25, 1.95, S, True, clamp_mode="relu", nerf_noise=0.5, white_back=True, _rng=rng)
+
+    eager = [t.clone() for t in call()]
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        call()                                        # warm-up on the capture stream (packing cache, allocator)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = call()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out[0], eager[0]) and torch.equal(out[1], eager[1])
+    fvol.mul_(-0.7)                                   # new inputs in the same buffers
+    glob.add_(0.3)
+    graph.replay()
+    torch.cuda.synchronize()
+    replayed = [t.clone() for t in out]
+    fresh = call()
+    assert torch.equal(replayed[0], fresh[0]) and torch.equal(replayed[1], fresh[1])
+    assert not torch.equal(replayed[0], eager[0])
