@@ -129,3 +129,19 @@ def test_philox_known_answers():
     assert u.min() >= 0 and u.max() < 1 and abs(u.mean() - 0.5) < 5e-3 and np.all(u * 2 ** 24 == np.round(u * 2 ** 24))
     n = P.normal(1234, 7, 1, 200000)
     assert abs(n.mean()) < 1e-2 and abs(n.std() - 1) < 1e-2 and np.isfinite(n).all()
+
+
+def test_philox_dropout_keep_layout():
+    """oracle/philox.py::dropout_keep (the NumPy twin of the kernels' dropout decisions): one Philox block per 4 consecutive
+    channels, counter index ((point * n_drop + d) * H + c) / 4, word c % 4 keeps iff >= round(p * 2^32)."""
+    from oracle import philox as P
+    seed, off, n_pts, n_drop, H, p = 77, 3, 50, 3, 64, 0.25
+    keep = P.dropout_keep(seed, off, 4, n_pts, n_drop, H, p)
+    assert keep.shape == (n_drop, n_pts, H) and keep.dtype == np.uint8 and set(np.unique(keep)) <= {0, 1}
+    assert abs(keep.mean() - (1 - p)) < 0.02
+    pt, d, c = 17, 2, 41                                  # one element by hand
+    idx = ((pt * n_drop + d) * H + c) // 4
+    words = P.philox4x32_10(idx & 0xFFFFFFFF, idx >> 32, 4, off, seed & 0xFFFFFFFF, seed >> 32)
+    assert keep[d, pt, c] == int(int(words[c % 4]) >= int(p * 2 ** 32 + 0.5))
+    assert not np.array_equal(keep, P.dropout_keep(seed, off, 5, n_pts, n_drop, H, p))      # the fine pass draws from its own stream
+    assert P.dropout_keep(seed, off, 4, n_pts, n_drop, H, 0.0).all()
