@@ -95,9 +95,20 @@ enum { EPI_FILM = 0, EPI_FILM_RES = 1 };
 #ifndef CNERF_F32_FOLD
 #define CNERF_F32_FOLD 1
 #endif
+// CNERF_F32_FOLD_ML = 0 (default) drops the low part of M, one vector op per activation less: M is then freq / 2 pi rounded to
+// fp32, a relative 6e-8, i.e. up to ~2e-6 revolutions on an argument of ~30 -- the size of ONE of the three roundings the
+// reference's own fp32 sequence makes at that magnitude.  Measured: 28.9 -> 28.4 ms per launch, parity unchanged (timed image of
+// bench.py: rgb / sigma 6.9e-5 / 7.8e-5 coarse / fine with Ml, 7.1e-5 / 7.2e-5 without; every parity test passes either way).
+#ifndef CNERF_F32_FOLD_ML
+#define CNERF_F32_FOLD_ML 0
+#endif
 __device__ __forceinline__ float folded_sine(float pre, float mh, float ml, float k) {
     const float n = __builtin_rintf(pre * mh);
+#if CNERF_F32_FOLD_ML
     return __builtin_amdgcn_sinf(__builtin_fmaf(pre, ml, __builtin_fmaf(pre, mh, -n)) + k);
+#else
+    return __builtin_amdgcn_sinf(__builtin_fmaf(pre, mh, -n) + k);
+#endif
 }
 
 template <int EPI, bool STORE>
