@@ -337,7 +337,7 @@ def pack_field_transposed(net, cfg):
 
 
 DEBUG_CAPTURE = None            # set to a dict to capture the backward's chunk buffers (scripts/debug_b16.py)
-ACT_BUDGET_BYTES = 48 << 30     # activation / gradient chunk buffers of the backward (288 GB HBM per GPU)
+ACT_BUDGET_BYTES = 128 << 30    # activation / gradient chunk buffers of the backward (288 GB HBM per GPU: batch 8 at 128x128x64 in one chunk)
 
 
 def _pfilm_backward(net, o, cfg, levels, cam2world, rng, saved, gc, gf):
