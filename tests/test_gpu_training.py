@@ -34,6 +34,33 @@ def test_gan_step_single_process():
     _run(ddp=False)
 
 
+@pytest.mark.parametrize("precisions", [("fp32", "fp32"), ("fp16x3", "fp16")])
+def test_gan_step_at_the_size_of_baseline_config_3(precisions):
+    """BASELINE config 3 as it is written: one full GAN step (UNet3D on 64^3 voxel grids -> 32 x 64^3 feature volume + global feature,
+    SHORTSIREN_FG hidden 256 rendered at 128x128 rays x (64 + 64) samples, ProgressiveDiscriminator with R1, Adam) -- batch 2, the
+    reference's chunk size at this stage (configs/thousand/special.py:24-30) -- through the HIP forward and backward, in the exact
+    arithmetic and in the fast one: finite losses, every generator parameter and the encoder updated, kept activations released.
+    (Convolutions in MIOpen's immediate mode: the kernel search that train.py turns on takes minutes.)"""
+    import cnerf_amd
+    from cnerf_amd.training import GanTrainer, default_metadata
+    from cnerf_amd.training.gan_step import synthetic_sample
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    md = default_metadata(img_size=128, num_steps=64, batch_size=2, batch_split=1, hidden_dim=256)
+    md["render_precision"], md["backward_precision"] = precisions
+    tr = GanTrainer(md, dev)
+    before = {k: v.detach().clone() for k, v in tr.generator.state_dict().items()}
+    enc_before = tr.encoder.final_conv.weight.detach().clone()
+    torch.cuda.reset_peak_memory_stats()
+    tr.step(synthetic_sample(2, 128, 64, dev, torch.Generator().manual_seed(3)))
+    torch.cuda.synchronize()
+    assert all(x == x and abs(x) < 1e4 for x in tr.losses["d"] + tr.losses["g"] + tr.losses["photo"])
+    assert all(not torch.equal(v, before[k]) for k, v in tr.generator.state_dict().items())
+    assert not torch.equal(tr.encoder.final_conv.weight, enc_before)
+    assert 0 < tr.last["g_grad_norm"] < 1e6 and 0 < tr.last["e_grad_norm"] < 1e6     # finite, non-zero gradients reached both networks
+    assert torch.cuda.max_memory_allocated() < 120 << 30
+
+
 def test_gan_step_ddp_one_rank_rccl():
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
