@@ -1011,6 +1011,14 @@ def test_backward_residual_blocks_vs_oracle_autograd(dev, shape, variant):
     _ragged_backward_case(dev, shape, variant, ("fp32", "fp16"))
 
 
+@pytest.mark.parametrize("variant", ["SHORTSIREN_FRes", "TALLSIREN_FG", "TALLSIREN"])
+def test_backward_with_dropout_vs_oracle_autograd(dev, variant):
+    """Training mode with drop_out > 0 at hidden 256 and ragged tiles, decisions injected on both sides: a network whose dropout
+    layers are interleaved with residual blocks (which have none: the layer counter of the decisions must skip them), the
+    eight-layer FiLM network and the per-point FiLM family, forward re-run and gradient chain against autograd through the oracle."""
+    _ragged_backward_case(dev, dict(B=2, R=4, S=9, V=6, H=256), variant, "fp32", drop_p=0.3)
+
+
 def test_benchmarked_shape_backward_vs_oracle_autograd(dev):
     """BASELINE configs 3/4 train at this shape: gradients of one image at 128x128 rays x (64 + 64) samples, 64^3 volume, hidden
     256 (two 32-point tiles per ray, 32 k tiles per pass, the LDS-resident head) against autograd through the CPU oracle on the
@@ -1019,7 +1027,7 @@ def test_benchmarked_shape_backward_vs_oracle_autograd(dev):
     _ragged_backward_case(dev, dict(B=1, R=128, S=64, V=64, H=256), "SHORTSIREN_FG", ("fp32", "fp16"))
 
 
-def _ragged_backward_case(dev, shape, variant, backward_precisions):
+def _ragged_backward_case(dev, shape, variant, backward_precisions, drop_p=0.0):
     import cnerf_amd
     from cnerf_amd.generators import ImplicitGenerator3d
     from cnerf_amd.generators.volumetric_rendering import sample_camera_positions, create_cam2world_matrix
@@ -1030,14 +1038,18 @@ def _ragged_backward_case(dev, shape, variant, backward_precisions):
     Z = 32
     from cnerf_amd.generators.siren import FIELD_SPECS
     has_glob = variant != "TALLSIREN" and FIELD_SPECS[variant].has_global
-    gen = (ImplicitGenerator3d(variant, Z, 32, 4, H) if has_glob else
-           ImplicitGenerator3d(variant, 32, 3 if variant == "TALLSIREN" else 32, 4, H))
+    gen = (ImplicitGenerator3d(variant, Z, 32, 4, H, drop_out=drop_p) if has_glob else
+           ImplicitGenerator3d(variant, 32, 3 if variant == "TALLSIREN" else 32, 4, H, drop_out=drop_p))
     with torch.no_grad():
         gen.siren.final_layer.weight[3] *= 20
     fvol, glob = torch.randn(B, 32, V, V, V) * 0.5, (torch.randn(B, Z) if has_glob else None)
     cam = create_cam2world_matrix(sample_camera_positions("cpu", "y", 0.7, 1.5, B), "y")
     P = R * R
     rng = {"u_strat": torch.rand(B, P, S), "eps_coarse": torch.randn(B, P, S), "u_fine": torch.rand(B, P, S), "eps_final": torch.randn(B, P, 2 * S)}
+    drop = {}
+    if drop_p:          # training mode: keep decisions of the two field passes, one (B, P*S, H) slab per FiLM / sine layer (not per residual block)
+        n_drop = sum(1 for k in gen.siren.spec.layers if k != "res")
+        drop = {k: (torch.rand(n_drop, B, P * S, H) >= drop_p).to(torch.uint8) for k in ("drop_coarse", "drop_fine")}
     def oracle_grads(dtype):
         c = lambda t: t.detach().clone().to(dtype)
         params = {k: c(v).requires_grad_(True) for k, v in gen.siren.state_dict().items()}
@@ -1046,7 +1058,7 @@ def _ragged_backward_case(dev, shape, variant, backward_precisions):
         try:
             ref = O.render(variant, params, fv_r, gl_r, c(cam), R, 49.13, 0.25, 1.95, S, True, "softplus", 0.3, True, False,
                            c(rng["u_strat"]), c(rng["eps_coarse"]), c(rng["u_fine"]), c(rng["eps_final"]),
-                           forced_fine_z=None if dtype == torch.float32 else forced)
+                           forced_fine_z=None if dtype == torch.float32 else forced, drop_p=drop_p, **drop)
         finally:
             torch.set_default_dtype(torch.float32)
         leaves = [fv_r] + ([gl_r] if has_glob else []) + list(params.values())
@@ -1061,7 +1073,7 @@ def _ragged_backward_case(dev, shape, variant, backward_precisions):
     gen.to(dev)
     gen.set_device(dev)
     gen.train()
-    r = {k: v.to(dev) for k, v in rng.items()}
+    r = {k: v.to(dev) for k, v in {**rng, **drop}.items()}
     r["fine_z"] = ref.aux["fine_z"].detach().to(dev)
     for backward_precision in ([backward_precisions] if isinstance(backward_precisions, str) else backward_precisions):
         gen.siren.precision = "fp32" if backward_precision == "fp32" else "fp16x3"
