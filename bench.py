@@ -343,7 +343,8 @@ def cpu_baseline(args, gen_cpu, fvol, glob, cam, draws):
             else:
                 times.append(dt)
     t = float(np.median(times)) if times else dt
-    return ({"value": R * R / t, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
+    mask = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    return ({"value": R * R / t, "unit": "rays/s", "cores": torch.get_num_threads(), "cores_in_affinity_mask": mask, "kind": "port",
              "sample": f"image 0 of the bench's own batch ({R}x{R}x{S} hierarchical fp32 no_grad), median of {max(args.cpu_reps, 1)} after 1 "
                        f"warm-up ({t:.2f} s each), oracle/render_oracle.py (ATen op sequence of the reference CPU path)"}, ref)
 
