@@ -170,6 +170,11 @@ static hipError_t pack_impl(const float* w, int n_out, int K_real, int OT, bool 
 #ifndef CNERF_H3_FOLD
 #define CNERF_H3_FOLD 1
 #endif
+// CNERF_H3_FOLD_ML = 0 drops Ml (M rounded to fp32: one vector op and one LDS read per activation pair less; the error is the
+// size of one of the reference's own roundings of the argument: see CNERF_F32_FOLD_ML in field_kernel.hip)
+#ifndef CNERF_H3_FOLD_ML
+#define CNERF_H3_FOLD_ML 0
+#endif
 
 struct FilmPair {
     f32x2 fr, ph, bs;       // FOLD (non-residual matrices): fr = Mh, ph = Ml, bs = K
@@ -221,11 +226,11 @@ __device__ __forceinline__ void film_split_pair(const f32x16& acc, float inv_s, 
     if (FOLD) {             // a0, a1 = the argument in revolutions, reduced to about [-1/2, 1/2] + K
         if (PHASE != 2) {
             const float n0 = __builtin_rintf(acc[r] * f.fr[0]);
-            a0 = __builtin_fmaf(acc[r], f.ph[0], __builtin_fmaf(acc[r], f.fr[0], -n0)) + f.bs[0];
+            a0 = (CNERF_H3_FOLD_ML ? __builtin_fmaf(acc[r], f.ph[0], __builtin_fmaf(acc[r], f.fr[0], -n0)) : __builtin_fmaf(acc[r], f.fr[0], -n0)) + f.bs[0];
         }
         if (PHASE != 1) {
             const float n1 = __builtin_rintf(acc[r + 1] * f.fr[1]);
-            a1 = __builtin_fmaf(acc[r + 1], f.ph[1], __builtin_fmaf(acc[r + 1], f.fr[1], -n1)) + f.bs[1];
+            a1 = (CNERF_H3_FOLD_ML ? __builtin_fmaf(acc[r + 1], f.ph[1], __builtin_fmaf(acc[r + 1], f.fr[1], -n1)) : __builtin_fmaf(acc[r + 1], f.fr[1], -n1)) + f.bs[1];
         }
     } else {
     if (PHASE != 2) a0 = __builtin_fmaf(acc[r], inv_s, f.bs[0]);
