@@ -255,9 +255,10 @@ int cnerf_workspace_bytes(const cnerf_cfg* cfg, size_t* packed, size_t* fvol_cl,
     }
     if (fwd_ws) {
         const size_t N = (size_t)cfg->B * cfg->R * cfg->R * cfg->S;
-        // coarse rgb_sigma + z, fine z + rgb_sigma; folded FiLM constants of the call (3 per image, FiLM layer and channel)
-        *fwd_ws = 2 * align256(N * 4 * sizeof(float)) + 2 * align256(N * sizeof(float)) +
-                  align256((size_t)3 * cfg->B * pl.n_film * cfg->H * sizeof(float));
+        // coarse rgb_sigma + z, fine z + rgb_sigma; folded FiLM constants of the call (3 per image, matrix and channel)
+        size_t mats = 0;
+        for (int l = 0; l < cfg->L; ++l) mats += cfg->layer_kind[l] == CNERF_LAYER_RES ? 2 : 1;
+        *fwd_ws = 2 * align256(N * 4 * sizeof(float)) + 2 * align256(N * sizeof(float)) + align256((size_t)3 * cfg->B * mats * cfg->H * sizeof(float));
     }
     return CNERF_OK;
 }
@@ -479,9 +480,10 @@ int cnerf_render_forward(const cnerf_cfg* cfg, const cnerf_volumes* vols, const 
     if (int rc = fill_field_args(fa, cfg, vols, nullptr, packed, freq, phase)) return rc;
     set_points(fa, cfg->B, npi);
     fa.cam2world = cam2world;
-    // all-FiLM network in the exact fp32 precision: FiLM folded into one affine map per channel, prepared once for both passes
-    if (cfg->precision == CNERF_PREC_FP32 && pl.n_film == cfg->L && cfg->drop_p == 0.0f) {
-        if (hipError_t e = launch_fold_film(freq, phase, (long long)cfg->B * pl.n_film * cfg->H, fold, stream)) return hip_fail(e, "fold_film");
+    // the exact fp32 precision: FiLM (plain sine: freq 1, phase 0) folded into one affine map per matrix and channel, prepared once
+    // for both passes (per-point FiLM computes its frequencies per point: not foldable)
+    if (cfg->precision == CNERF_PREC_FP32 && cfg->layer_kind[0] != CNERF_LAYER_PFILM && cfg->drop_p == 0.0f) {
+        if (hipError_t e = launch_fold_film(fa, cfg->B, cfg->H, fold, stream)) return hip_fail(e, "fold_film");
         fa.fold = fold;
         fa.fold_images = cfg->B;
     }

@@ -86,7 +86,8 @@ constexpr int RING = CNERF_RING;
 // epilogue kinds
 enum { EPI_FILM = 0, EPI_FILM_RES = 1 };
 
-// FOLD (all-FiLM networks, plain forward): arg = freq * pre + phase is affine in the accumulator (which already holds the bias)
+// FOLD (plain forward of cnerf_render_forward): arg = freq * pre + phase is affine in the accumulator (which already holds the bias;
+// a plain sine layer or a residual matrix is freq = 1, phase = 0, with the block input added to pre first)
 // and v_sin_f32 takes revolutions, so with the per-image constants M = freq / 2 pi = Mh + Ml and K = phase / 2 pi
 // (fold_film_kernel, once per call) the activation is  n = rint(pre Mh);  u = fma(pre, Ml, fma(pre, Mh, -n)) + K;  sin(2 pi u):
 // 5 vector ops + v_sin instead of 2 + the 12-op reduce-and-polynomial sine.  pre * Mh - n is a single-rounding fma of
@@ -185,7 +186,7 @@ __device__ __forceinline__ void mlp_matrix(const f32x4* __restrict__ wp, const f
                 for (int q = 0; q < EPG; ++q) {
                     const int r = (gi / ESTEP) * EPG + q;
                     float cs_ = 0.0f;
-                    if (FOLD) out[t - 1][r] = folded_sine(acc_prev[r], fr_prev[r], ml_prev[r], ph_prev[r]);
+                    if (FOLD) out[t - 1][r] = folded_sine(EPI == EPI_FILM_RES ? res[t - 1][r] + acc_prev[r] : acc_prev[r], fr_prev[r], ml_prev[r], ph_prev[r]);
                     else out[t - 1][r] = epilogue_one<EPI, STORE>(acc_prev[r], EPI == EPI_FILM_RES ? res[t - 1][r] : 0.0f, fr_prev[r],
                                                                   ph_prev[r], cs_);
                     if (STORE) cos_t[r] = cs_;
@@ -209,7 +210,7 @@ __device__ __forceinline__ void mlp_matrix(const f32x4* __restrict__ wp, const f
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         float cs_ = 0.0f;
-        if (FOLD) out[OT - 1][r] = folded_sine(acc_prev[r], fr_prev[r], ml_prev[r], ph_prev[r]);
+        if (FOLD) out[OT - 1][r] = folded_sine(EPI == EPI_FILM_RES ? res[OT - 1][r] + acc_prev[r] : acc_prev[r], fr_prev[r], ml_prev[r], ph_prev[r]);
         else out[OT - 1][r] = epilogue_one<EPI, STORE>(acc_prev[r], EPI == EPI_FILM_RES ? res[OT - 1][r] : 0.0f, fr_prev[r], ph_prev[r],
                                                        cs_);
         if (STORE) cos_t[r] = cs_;
@@ -386,9 +387,10 @@ __global__ __launch_bounds__(256) void field_tile_kernel(FieldArgs a) {
         const float* ones = a.bias + a.bias_floats;
         const float* zeros = ones + H;
         // FOLD: `freq` / `phase` walk the folded constants Mh / K of the image instead, `fml` the low parts Ml (a.fold: three
-        // arrays of (B, film_stride) floats: Mh, Ml, K)
-        const size_t fold_n = FOLD ? (size_t)a.fold_images * a.film_stride : 0;
-        const float* freq = FOLD ? a.fold + (size_t)(b + a.image0) * a.film_stride : (a.freq ? a.freq + (size_t)b * a.film_stride : nullptr);
+        // arrays of (B, n_mats * H) floats: Mh, Ml, K -- one H-vector per MATRIX, whatever its layer kind)
+        const size_t fold_stride = (size_t)a.n_mats * H;
+        const size_t fold_n = FOLD ? (size_t)a.fold_images * fold_stride : 0;
+        const float* freq = FOLD ? a.fold + (size_t)(b + a.image0) * fold_stride : (a.freq ? a.freq + (size_t)b * a.film_stride : nullptr);
         const float* phase = FOLD ? freq + 2 * fold_n : (a.phase ? a.phase + (size_t)b * a.film_stride : nullptr);
         const float* fml = FOLD ? freq + fold_n : nullptr;
 #pragma unroll
@@ -410,14 +412,14 @@ __global__ __launch_bounds__(256) void field_tile_kernel(FieldArgs a) {
         STAMP(1);   // position + lookups + layer-0 products
         {
             const bool film = a.layer_kind[0] == CNERF_LAYER_FILM;
-            film_all<NT, STORE, DROP, FOLD>(y.v, x.v, film ? freq : ones, film ? phase : zeros, h, row_h, row_c, &a, drop_gp, fml);
+            film_all<NT, STORE, DROP, FOLD>(y.v, x.v, (FOLD || film) ? freq : ones, (FOLD || film) ? phase : zeros, h, row_h, row_c, &a, drop_gp, fml);
             if (STORE) {
                 row_h += act_layer;
                 row_c += act_layer;
             }
             wp += (size_t)NT * a.n_in * TILE4;
             bias += H;
-            if (film) {
+            if (FOLD || film) {
                 freq += H;
                 phase += H;
                 if (FOLD) fml += H;
@@ -430,15 +432,15 @@ __global__ __launch_bounds__(256) void field_tile_kernel(FieldArgs a) {
             if (!HAS_RES || kind != CNERF_LAYER_RES) {
                 const bool film = kind == CNERF_LAYER_FILM;
                 ++drop_d;
-                mlp_matrix<NT, NT, EPI_FILM, STORE, DROP, FOLD>(wp, bias, film ? freq : ones, film ? phase : zeros, x.v, nullptr, y.v, lane,
-                                                                h, row_h, row_c, &a, drop_gp, drop_d, fml);
+                mlp_matrix<NT, NT, EPI_FILM, STORE, DROP, FOLD>(wp, bias, (FOLD || film) ? freq : ones, (FOLD || film) ? phase : zeros, x.v, nullptr,
+                                                                y.v, lane, h, row_h, row_c, &a, drop_gp, drop_d, fml);
                 if (STORE) {
                     row_h += act_layer;
                     row_c += act_layer;
                 }
                 wp += (size_t)NT * NT * TILE4;
                 bias += H;
-                if (film) {
+                if (FOLD || film) {
                     freq += H;
                     phase += H;
                     if (FOLD) fml += H;
@@ -449,14 +451,26 @@ __global__ __launch_bounds__(256) void field_tile_kernel(FieldArgs a) {
                 STAMP(3);   // hidden layers
             } else {
                 // y = sin(W1 x + b1);  x = sin(x + W2 y + b2)   (tile t of x is dead once its own residual is added)
-                mlp_matrix<NT, NT, EPI_FILM, STORE>(wp, bias, ones, zeros, x.v, nullptr, y.v, lane, h, row_h, row_c);
+                mlp_matrix<NT, NT, EPI_FILM, STORE, false, FOLD>(wp, bias, FOLD ? freq : ones, FOLD ? phase : zeros, x.v, nullptr, y.v, lane, h, row_h,
+                                                                 row_c, nullptr, 0, 0, fml);
                 if (STORE) {
                     row_h += act_layer;
                     row_c += act_layer;
                 }
                 wp += (size_t)NT * NT * TILE4;
                 bias += H;
-                mlp_matrix<NT, NT, EPI_FILM_RES, STORE>(wp, bias, ones, zeros, y.v, x.v, x.v, lane, h, row_h, row_c);
+                if (FOLD) {
+                    freq += H;
+                    phase += H;
+                    fml += H;
+                }
+                mlp_matrix<NT, NT, EPI_FILM_RES, STORE, false, FOLD>(wp, bias, FOLD ? freq : ones, FOLD ? phase : zeros, y.v, x.v, x.v, lane, h, row_h,
+                                                                     row_c, nullptr, 0, 0, fml);
+                if (FOLD) {
+                    freq += H;
+                    phase += H;
+                    fml += H;
+                }
                 if (STORE) {
                     row_h += act_layer;
                     row_c += act_layer;
@@ -990,20 +1004,42 @@ hipError_t launch_fill(float* dst, float value, int n, hipStream_t stream) {
     return hipGetLastError();
 }
 
-// folded FiLM constants of a call (see folded_sine): out = [Mh | Ml | K], n = B * film_stride floats each
-__global__ void fold_film_kernel(const float* __restrict__ freq, const float* __restrict__ phase, long long n, float* __restrict__ out) {
+// folded FiLM constants of a call (see folded_sine): out = [Mh | Ml | K], each (B, n_mats, H): one H-vector per image and MATRIX;
+// film_of[m] = index of matrix m's FiLM vectors inside an image's (film_stride) freq / phase rows, or -1 (plain sine layer,
+// residual matrix: freq = 1, phase = 0)
+struct FoldMap {
+    int film_of[2 * CNERF_MAX_LAYERS];
+};
+__global__ void fold_film_kernel(const float* __restrict__ freq, const float* __restrict__ phase, FoldMap map, int B, int n_mats, int H,
+                                 int film_stride, float* __restrict__ out) {
+    const long long n = (long long)B * n_mats * H;
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
-        const double M = (double)freq[i] * 0.15915494309189533577;
+        const int ch = (int)(i % H), m = (int)((i / H) % n_mats), b = (int)(i / ((long long)H * n_mats));
+        const int f = map.film_of[m];
+        const double fr = f >= 0 ? (double)freq[(size_t)b * film_stride + (size_t)f * H + ch] : 1.0;
+        const double ph = f >= 0 ? (double)phase[(size_t)b * film_stride + (size_t)f * H + ch] : 0.0;
+        const double M = fr * 0.15915494309189533577;
         const float mh = (float)M;
         out[i] = mh;
         out[n + i] = (float)(M - (double)mh);
-        out[2 * n + i] = (float)((double)phase[i] * 0.15915494309189533577);
+        out[2 * n + i] = (float)(ph * 0.15915494309189533577);
     }
 }
 
-hipError_t launch_fold_film(const float* freq, const float* phase, long long n, float* out, hipStream_t stream) {
-    hipLaunchKernelGGL(fold_film_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, freq, phase, n, out);
+hipError_t launch_fold_film(const FieldArgs& a, int B, int H, float* out, hipStream_t stream) {
+    FoldMap map;
+    int m = 0, films = 0;
+    for (int l = 0; l < a.L; ++l) {
+        if (a.layer_kind[l] == CNERF_LAYER_RES) {
+            map.film_of[m++] = -1;
+            map.film_of[m++] = -1;
+        } else {
+            map.film_of[m++] = a.layer_kind[l] == CNERF_LAYER_FILM ? films++ : -1;
+        }
+    }
+    const long long n = (long long)B * a.n_mats * H;
+    hipLaunchKernelGGL(fold_film_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a.freq, a.phase, map, B, a.n_mats, H, a.film_stride, out);
     return hipGetLastError();
 }
 
@@ -1092,7 +1128,7 @@ static hipError_t launch_field_nt(const FieldArgs& a, hipStream_t stream) {
     // a.act_h set: activation-storing forward of the backward pass; a.drop_scale != 0: dropout (training mode)
     if (a.drop_scale != 0.0f)
         return a.act_h ? launch_field_tile<NT, HAS_RES, true, true>(a, stream) : launch_field_tile<NT, HAS_RES, false, true>(a, stream);
-    if (CNERF_F32_FOLD && !HAS_RES && a.fold && !a.act_h) return launch_field_tile<NT, false, false, false, true>(a, stream);
+    if (CNERF_F32_FOLD && a.fold && !a.act_h) return launch_field_tile<NT, HAS_RES, false, false, true>(a, stream);
     return a.act_h ? launch_field_tile<NT, HAS_RES, true, false>(a, stream) : launch_field_tile<NT, HAS_RES, false, false>(a, stream);
 }
 
