@@ -192,3 +192,28 @@ def test_two_rank_gan_step_parameters_and_allreduce_count():
     assert all(v > 0 for v in n1.values())
     assert c1_0 == n1 and c1_1 == n1, (c1_0, n1)                 # four chunks, one all-reduce round
     assert c2_0 == {k: 2 * v for k, v in n1.items()}             # and again in the second step
+
+
+@pytest.mark.parametrize("batch_split", [1, 2])
+def test_keeping_the_encoder_output_between_the_d_and_g_pass_changes_nothing(batch_split):
+    """GanTrainer.step with metadata["reuse_encoder_output"] (one encoder forward per chunk, shared by the D step's no-grad renders
+    and the G step's backward) must end a step with exactly the parameters of the reference's schedule (encoder re-evaluated in the G
+    step): same initial state, same batch, same NumPy camera draws."""
+    import numpy as np
+    import cnerf_amd  # noqa: F401
+    from cnerf_amd.training import GanTrainer, default_metadata
+    from cnerf_amd.training.gan_step import synthetic_sample
+    out = []
+    for reuse in (True, False):
+        torch.manual_seed(0)
+        md = default_metadata(img_size=16, num_steps=4, batch_size=4, batch_split=batch_split, hidden_dim=64)
+        md["unet"].update(f_maps=8, num_levels=2)
+        md["reuse_encoder_output"] = reuse
+        tr = GanTrainer(md, torch.device("cpu"), modules={"generator": _StandInGenerator(16)})
+        np.random.seed(99)
+        sample = synthetic_sample(4, 16, 8, "cpu", torch.Generator().manual_seed(99))
+        for _ in range(2):
+            np.random.seed(1234)
+            tr.step(sample)
+        out.append(torch.cat([p.detach().flatten() for m in (tr.generator, tr.encoder, tr.discriminator) for p in m.parameters()]))
+    assert torch.allclose(out[0], out[1], rtol=0, atol=1e-7)
