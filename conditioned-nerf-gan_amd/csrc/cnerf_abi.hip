@@ -258,7 +258,11 @@ int cnerf_workspace_bytes(const cnerf_cfg* cfg, size_t* packed, size_t* fvol_cl,
         // coarse rgb_sigma + z, fine z + rgb_sigma; folded FiLM constants of the call (3 per image, matrix and channel)
         size_t mats = 0;
         for (int l = 0; l < cfg->L; ++l) mats += cfg->layer_kind[l] == CNERF_LAYER_RES ? 2 : 1;
-        *fwd_ws = 2 * align256(N * 4 * sizeof(float)) + 2 * align256(N * sizeof(float)) + align256((size_t)3 * cfg->B * mats * cfg->H * sizeof(float));
+        // ... 4 per image, matrix and channel; and, for all-FiLM networks in fp32, the row-scaled layer weights per image
+        const size_t NT = cfg->H / 32;
+        const size_t layer_floats = (NT * pl.n_in + (mats - 1) * NT * NT) * 1024;
+        *fwd_ws = 2 * align256(N * 4 * sizeof(float)) + 2 * align256(N * sizeof(float)) + align256((size_t)4 * cfg->B * mats * cfg->H * sizeof(float)) +
+                  align256((size_t)cfg->B * layer_floats * sizeof(float));
     }
     return CNERF_OK;
 }
@@ -469,6 +473,12 @@ int cnerf_render_forward(const cnerf_cfg* cfg, const cnerf_volumes* vols, const 
     float* c_z = (float*)ws;  ws += align256(N * sizeof(float));
     float* f_z = (float*)ws;  ws += align256(N * sizeof(float));
     float* fold = (float*)ws;
+    {
+        size_t mats = 0;
+        for (int l = 0; l < cfg->L; ++l) mats += cfg->layer_kind[l] == CNERF_LAYER_RES ? 2 : 1;
+        ws += align256((size_t)4 * cfg->B * mats * cfg->H * sizeof(float));
+    }
+    float* packed_img = (float*)ws;
     if (aux) {   // write straight into the caller's buffers where given
         if (aux->coarse_rgb_sigma) c_rs = aux->coarse_rgb_sigma;
         if (aux->fine_rgb_sigma) f_rs = aux->fine_rgb_sigma;
@@ -486,6 +496,13 @@ int cnerf_render_forward(const cnerf_cfg* cfg, const cnerf_volumes* vols, const 
         if (hipError_t e = launch_fold_film(fa, cfg->B, cfg->H, fold, stream)) return hip_fail(e, "fold_film");
         fa.fold = fold;
         fa.fold_images = cfg->B;
+        if (pl.n_film == cfg->L) {        // all-FiLM: the scale goes into per-image copies of the layer weights (WFOLD, field_kernel.hip)
+            const size_t NT = cfg->H / 32;
+            const long long layer_floats = (long long)((NT * pl.n_in + (size_t)(cfg->L - 1) * NT * NT) * 1024);
+            if (hipError_t e = launch_scale_packed(fa, cfg->B, cfg->H, fold, layer_floats, packed_img, stream)) return hip_fail(e, "scale_packed");
+            fa.packed_img = packed_img;
+            fa.packed_img_stride = layer_floats;
+        }
     }
     // 1. coarse pass
     fa.mode = FIELD_MODE_COARSE;

@@ -67,13 +67,16 @@ struct FieldArgs {
     long long drop_points;   // points of the whole call (B * n_per_image): row count of one layer of drop_mask
     const uint8_t* drop_mask;  // injected keep decisions (n_drop, drop_points, H), 1 = keep; null: Philox
     // folded FiLM constants of the call (field_tile_kernel FOLD: all-FiLM networks, plain fp32 forward), or null
-    const float* fold;       // [Mh | Ml | K], each (fold_images, n_mats, H)
+    const float* fold;       // [Mh | Ml | K | Kb], each (fold_images, n_mats, H)
     int fold_images;
+    const float* packed_img; // WFOLD: per image, the layer part of the packed weights with rows scaled by Mh (scale_packed_kernel), or null
+    long long packed_img_stride;
 };
 
 hipError_t launch_fill(float* dst, float value, int n, hipStream_t stream);
 hipError_t launch_pack_matrix(const float* w, int n_out, int K_real, int OT, float* dst, hipStream_t stream);
 hipError_t launch_fold_film(const FieldArgs& a, int B, int H, float* out, hipStream_t stream);
+hipError_t launch_scale_packed(const FieldArgs& a, int B, int H, const float* mh, long long layer_floats, float* out, hipStream_t stream);
 hipError_t launch_field(const FieldArgs& a, int H, hipStream_t stream);
 hipError_t launch_field_h3(const FieldArgs& a, int H, hipStream_t stream);
 hipError_t launch_field_h1(const FieldArgs& a, int H, hipStream_t stream);      // field_h3.hip compiled with CNERF_H3_PARTS=1

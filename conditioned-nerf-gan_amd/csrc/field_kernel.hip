@@ -112,6 +112,15 @@ __device__ __forceinline__ float folded_sine(float pre, float mh, float ml, floa
 #endif
 }
 
+// WFOLD (all-FiLM networks): the scale is folded into the WEIGHTS, per image -- W'_b = diag(freq_b / 2 pi) W, packed per call into the
+// workspace (scale_packed_kernel), the accumulator starts from K_b = (freq_b bias + phase_b) / 2 pi -- so the accumulator IS the
+// argument in revolutions and the activation is sin(2 pi (acc - rint(acc))): two vector ops + v_sin, no per-channel constants in the
+// epilogue.  Numerically the sum is rounded at the same relative precision as before; the weights carry one more rounding (6e-8).
+#ifndef CNERF_F32_WFOLD
+#define CNERF_F32_WFOLD 1
+#endif
+__device__ __forceinline__ float wfolded_sine(float u) { return __builtin_amdgcn_sinf(u - __builtin_rintf(u)); }
+
 template <int EPI, bool STORE>
 __device__ __forceinline__ float epilogue_one(float acc, float res, float fr, float ph, float& cs) {
     float pre = acc;
@@ -147,7 +156,7 @@ __device__ __forceinline__ void store_tile_rows(float* __restrict__ row /* &buf[
 // full 2 cycles whether spread between the MFMAs or clumped, with one or two accumulator chains -- so for the fp32
 // path  time = MFMA + VALU + stalls  and the epilogue placement only matters for register pressure and load distance.
 // DROP: the finished tile (and its cosine row) is multiplied by the dropout factors of layer `drop_d` at point `drop_gp`.
-template <int OT, int KT, int EPI, bool STORE, bool DROP = false, bool FOLD = false>
+template <int OT, int KT, int EPI, bool STORE, bool DROP = false, bool FOLD = false, bool WFOLD = false>
 __device__ __forceinline__ void mlp_matrix(const f32x4* __restrict__ wp, const float* __restrict__ bias,
                                            const float* __restrict__ freq, const float* __restrict__ phase,
                                            const f32x16* in, const f32x16* res, f32x16* out, int lane, int h,
@@ -168,10 +177,12 @@ __device__ __forceinline__ void mlp_matrix(const f32x4* __restrict__ wp, const f
     for (int t = 0; t < OT; ++t) {
         f32x16 acc = bias_next;
         if (t + 1 < OT) bias_next = load_chan16(bias, t + 1, h);
-        const f32x16 fr = load_chan16(freq, t, h);
-        const f32x16 ph = load_chan16(phase, t, h);
-        f32x16 ml;
-        if (FOLD) ml = load_chan16(fold_ml, t, h);
+        f32x16 fr, ph, ml;
+        if (!WFOLD) {
+            fr = load_chan16(freq, t, h);
+            ph = load_chan16(phase, t, h);
+        }
+        if (FOLD && !WFOLD) ml = load_chan16(fold_ml, t, h);
 #pragma unroll
         for (int gi = 0; gi < GPT; ++gi) {
             const int tk = gi >> 2, g = gi & 3;
@@ -186,7 +197,8 @@ __device__ __forceinline__ void mlp_matrix(const f32x4* __restrict__ wp, const f
                 for (int q = 0; q < EPG; ++q) {
                     const int r = (gi / ESTEP) * EPG + q;
                     float cs_ = 0.0f;
-                    if (FOLD) out[t - 1][r] = folded_sine(EPI == EPI_FILM_RES ? res[t - 1][r] + acc_prev[r] : acc_prev[r], fr_prev[r], ml_prev[r], ph_prev[r]);
+                    if (WFOLD) out[t - 1][r] = wfolded_sine(acc_prev[r]);
+                    else if (FOLD) out[t - 1][r] = folded_sine(EPI == EPI_FILM_RES ? res[t - 1][r] + acc_prev[r] : acc_prev[r], fr_prev[r], ml_prev[r], ph_prev[r]);
                     else out[t - 1][r] = epilogue_one<EPI, STORE>(acc_prev[r], EPI == EPI_FILM_RES ? res[t - 1][r] : 0.0f, fr_prev[r],
                                                                   ph_prev[r], cs_);
                     if (STORE) cos_t[r] = cs_;
@@ -203,14 +215,17 @@ __device__ __forceinline__ void mlp_matrix(const f32x4* __restrict__ wp, const f
             __builtin_amdgcn_sched_barrier(0);
         }
         acc_prev = acc;
-        fr_prev = fr;
-        ph_prev = ph;
-        if (FOLD) ml_prev = ml;
+        if (!WFOLD) {
+            fr_prev = fr;
+            ph_prev = ph;
+        }
+        if (FOLD && !WFOLD) ml_prev = ml;
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         float cs_ = 0.0f;
-        if (FOLD) out[OT - 1][r] = folded_sine(EPI == EPI_FILM_RES ? res[OT - 1][r] + acc_prev[r] : acc_prev[r], fr_prev[r], ml_prev[r], ph_prev[r]);
+        if (WFOLD) out[OT - 1][r] = wfolded_sine(acc_prev[r]);
+        else if (FOLD) out[OT - 1][r] = folded_sine(EPI == EPI_FILM_RES ? res[OT - 1][r] + acc_prev[r] : acc_prev[r], fr_prev[r], ml_prev[r], ph_prev[r]);
         else out[OT - 1][r] = epilogue_one<EPI, STORE>(acc_prev[r], EPI == EPI_FILM_RES ? res[OT - 1][r] : 0.0f, fr_prev[r], ph_prev[r],
                                                        cs_);
         if (STORE) cos_t[r] = cs_;
@@ -248,7 +263,7 @@ __device__ __forceinline__ void layer0_accumulate(const f32x4* __restrict__ wp, 
 }
 
 // x[t] = sin(freq * y[t] + phase) for all tiles (+ activation store)
-template <int NT, bool STORE, bool DROP = false, bool FOLD = false>
+template <int NT, bool STORE, bool DROP = false, bool FOLD = false, bool WFOLD = false>
 __device__ __forceinline__ void film_all(const f32x16* y, f32x16* x, const float* __restrict__ freq,
                                          const float* __restrict__ phase, int h, float* row_h, float* row_c,
                                          const FieldArgs* da = nullptr, unsigned long long drop_gp = 0,
@@ -266,7 +281,10 @@ __device__ __forceinline__ void film_all(const f32x16* y, f32x16* x, const float
         const f32x16 fr = t == 0 ? fr_n : load_chan16(freq, t, h), ph = t == 0 ? ph_n : load_chan16(phase, t, h);
 #endif
         f32x16 o, cs;
-        if (FOLD) {
+        if (WFOLD) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[r] = wfolded_sine(y[t][r]);
+        } else if (FOLD) {
             const f32x16 ml = load_chan16(fold_ml, t, h);
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[r] = folded_sine(y[t][r], fr[r], ml[r], ph[r]);
@@ -319,7 +337,7 @@ __device__ __forceinline__ void film_all(const f32x16* y, f32x16* x, const float
 #define CNERF_F32_LOOKUP_DMA 0
 #endif
 
-template <int NT, bool HAS_RES, bool STORE, bool DROP, bool FOLD = false>
+template <int NT, bool HAS_RES, bool STORE, bool DROP, bool FOLD = false, bool WFOLD = false>
 __global__ __launch_bounds__(256) void field_tile_kernel(FieldArgs a) {
 #ifdef CNERF_STAMPS
     unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -382,8 +400,9 @@ __global__ __launch_bounds__(256) void field_tile_kernel(FieldArgs a) {
         const size_t act_layer = (size_t)a.act_points * H;                 // floats per layer in act_h / act_c
         float* row_h = STORE ? a.act_h + gpt * H : nullptr;
         float* row_c = STORE ? a.act_c + gpt * H : nullptr;
-        const f32x4* wp = reinterpret_cast<const f32x4*>(a.packed);
-        const float* bias = a.bias;              // concatenated biases, layer after layer (H each, RES: 2H)
+        // WFOLD: this image's row-scaled weights; `bias` walks K_b = (freq bias + phase) / 2 pi, the accumulators' starting values
+        const f32x4* wp = reinterpret_cast<const f32x4*>(WFOLD ? a.packed_img + (size_t)(b + a.image0) * a.packed_img_stride : a.packed);
+        const float* bias = WFOLD ? a.fold + 3 * (size_t)a.fold_images * a.n_mats * H + (size_t)(b + a.image0) * a.n_mats * H : a.bias;
         const float* ones = a.bias + a.bias_floats;
         const float* zeros = ones + H;
         // FOLD: `freq` / `phase` walk the folded constants Mh / K of the image instead, `fml` the low parts Ml (a.fold: three
@@ -412,7 +431,7 @@ __global__ __launch_bounds__(256) void field_tile_kernel(FieldArgs a) {
         STAMP(1);   // position + lookups + layer-0 products
         {
             const bool film = a.layer_kind[0] == CNERF_LAYER_FILM;
-            film_all<NT, STORE, DROP, FOLD>(y.v, x.v, (FOLD || film) ? freq : ones, (FOLD || film) ? phase : zeros, h, row_h, row_c, &a, drop_gp, fml);
+            film_all<NT, STORE, DROP, FOLD, WFOLD>(y.v, x.v, (FOLD || film) ? freq : ones, (FOLD || film) ? phase : zeros, h, row_h, row_c, &a, drop_gp, fml);
             if (STORE) {
                 row_h += act_layer;
                 row_c += act_layer;
@@ -432,8 +451,8 @@ __global__ __launch_bounds__(256) void field_tile_kernel(FieldArgs a) {
             if (!HAS_RES || kind != CNERF_LAYER_RES) {
                 const bool film = kind == CNERF_LAYER_FILM;
                 ++drop_d;
-                mlp_matrix<NT, NT, EPI_FILM, STORE, DROP, FOLD>(wp, bias, (FOLD || film) ? freq : ones, (FOLD || film) ? phase : zeros, x.v, nullptr,
-                                                                y.v, lane, h, row_h, row_c, &a, drop_gp, drop_d, fml);
+                mlp_matrix<NT, NT, EPI_FILM, STORE, DROP, FOLD, WFOLD>(wp, bias, (FOLD || film) ? freq : ones, (FOLD || film) ? phase : zeros, x.v,
+                                                                       nullptr, y.v, lane, h, row_h, row_c, &a, drop_gp, drop_d, fml);
                 if (STORE) {
                     row_h += act_layer;
                     row_c += act_layer;
@@ -487,10 +506,13 @@ __global__ __launch_bounds__(256) void field_tile_kernel(FieldArgs a) {
 
         // ---- head: 4 outputs on the 4x4x1 MFMA (16 blocks of 4 points), see pack_head_kernel -------------------------------
         {
+            // (WFOLD: `bias` / `wp` walked the per-image constants / weights: the head's own bias and weights are the shared ones)
+            const float* head_bias = WFOLD ? a.bias + (size_t)a.n_mats * H : bias;
 #if CNERF_F32_HEAD_LDS
-            const f32x4 acc = head_forward<NT>(s_head, bias, x.v, lane);
+            const f32x4 acc = head_forward<NT>(s_head, head_bias, x.v, lane);
 #else
-            const f32x4 acc = head_forward<NT>(wp, bias, x.v, lane);
+            const f32x4* head_wp = WFOLD ? reinterpret_cast<const f32x4*>(a.packed) + ((size_t)NT * a.n_in + (size_t)(a.n_mats - 1) * NT * NT) * TILE4 : wp;
+            const f32x4 acc = head_forward<NT>(head_wp, head_bias, x.v, lane);
 #endif
             if (valid && h == 0) {
                 f32x4 o;
@@ -1004,14 +1026,14 @@ hipError_t launch_fill(float* dst, float value, int n, hipStream_t stream) {
     return hipGetLastError();
 }
 
-// folded FiLM constants of a call (see folded_sine): out = [Mh | Ml | K], each (B, n_mats, H): one H-vector per image and MATRIX;
+// folded FiLM constants of a call (see folded_sine): out = [Mh | Ml | K | Kb], each (B, n_mats, H): one H-vector per image and MATRIX;
 // film_of[m] = index of matrix m's FiLM vectors inside an image's (film_stride) freq / phase rows, or -1 (plain sine layer,
 // residual matrix: freq = 1, phase = 0)
 struct FoldMap {
     int film_of[2 * CNERF_MAX_LAYERS];
 };
-__global__ void fold_film_kernel(const float* __restrict__ freq, const float* __restrict__ phase, FoldMap map, int B, int n_mats, int H,
-                                 int film_stride, float* __restrict__ out) {
+__global__ void fold_film_kernel(const float* __restrict__ freq, const float* __restrict__ phase, const float* __restrict__ bias, FoldMap map,
+                                 int B, int n_mats, int H, int film_stride, float* __restrict__ out) {
     const long long n = (long long)B * n_mats * H;
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
@@ -1024,7 +1046,47 @@ __global__ void fold_film_kernel(const float* __restrict__ freq, const float* __
         out[i] = mh;
         out[n + i] = (float)(M - (double)mh);
         out[2 * n + i] = (float)(ph * 0.15915494309189533577);
+        // WFOLD: the accumulator's starting value, bias included (one rounding)
+        out[3 * n + i] = (float)(M * (double)bias[(size_t)m * H + ch] + ph * 0.15915494309189533577);
     }
+}
+
+// WFOLD: out[b] = the layer part of the packed weight stream with every row scaled by Mh[b][matrix][row]
+// (packed layout: float index ((t * KT + tk) * 4 + g) * 256 + lane * 4 + e  <->  row 32 t + (lane & 31); layer 0 has n_in k-tiles)
+__global__ void scale_packed_kernel(const float* __restrict__ packed, const float* __restrict__ mh, const float* __restrict__ ml, int n_in, int NT,
+                                    int n_mats, long long layer_floats, float* __restrict__ out) {
+    const int b = blockIdx.y;
+    const int H = NT * 32;
+    const long long l0 = (long long)NT * n_in * 1024, lh = (long long)NT * NT * 1024;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < layer_floats; idx += (long long)gridDim.x * blockDim.x) {
+        int m;
+        long long li;
+        int KT;
+        if (idx < l0) {
+            m = 0;
+            li = idx;
+            KT = n_in;
+        } else {
+            m = 1 + (int)((idx - l0) / lh);
+            li = (idx - l0) - (long long)(m - 1) * lh;
+            KT = NT;
+        }
+        const int lane = (int)((li >> 2) & 63);
+        const long long rest = li >> 10;
+        const int t = (int)(rest / KT);
+        const int row = 32 * t + (lane & 31);
+        const size_t mi = ((size_t)b * n_mats + m) * H + row;
+        out[(size_t)b * layer_floats + idx] = (float)((double)packed[idx] * ((double)mh[mi] + (double)ml[mi]));      // M = Mh + Ml: one rounding
+    }
+}
+
+hipError_t launch_scale_packed(const FieldArgs& a, int B, int H, const float* mh, long long layer_floats, float* out, hipStream_t stream) {
+    long long bx = (layer_floats + 255) / 256;
+    if (bx > 1024) bx = 1024;
+    const float* ml = mh + (size_t)B * a.n_mats * H;                 // fold = [Mh | Ml | K | Kb]
+    hipLaunchKernelGGL(scale_packed_kernel, dim3((unsigned)bx, (unsigned)B), dim3(256), 0, stream, a.packed, mh, ml, a.n_in, H / 32, a.n_mats, layer_floats,
+                       out);
+    return hipGetLastError();
 }
 
 hipError_t launch_fold_film(const FieldArgs& a, int B, int H, float* out, hipStream_t stream) {
@@ -1039,7 +1101,8 @@ hipError_t launch_fold_film(const FieldArgs& a, int B, int H, float* out, hipStr
         }
     }
     const long long n = (long long)B * a.n_mats * H;
-    hipLaunchKernelGGL(fold_film_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a.freq, a.phase, map, B, a.n_mats, H, a.film_stride, out);
+    hipLaunchKernelGGL(fold_film_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a.freq, a.phase, a.bias, map, B, a.n_mats, H,
+                       a.film_stride, out);
     return hipGetLastError();
 }
 
@@ -1110,16 +1173,16 @@ hipError_t launch_field_backward(const FieldArgs& a, int H, hipStream_t stream) 
     }
 }
 
-template <int NT, bool HAS_RES, bool STORE, bool DROP, bool FOLD = false>
+template <int NT, bool HAS_RES, bool STORE, bool DROP, bool FOLD = false, bool WFOLD = false>
 static hipError_t launch_field_tile(const FieldArgs& a, hipStream_t stream) {
     if (a.n_in < 1 || a.in_level[0] < 0) return hipErrorInvalidValue;      // the lookup prefetch assumes a volume tile first
-    const void* fn = (const void*)field_tile_kernel<NT, HAS_RES, STORE, DROP, FOLD>;
+    const void* fn = (const void*)field_tile_kernel<NT, HAS_RES, STORE, DROP, FOLD, WFOLD>;
     const int lds_bytes = (CNERF_F32_LOOKUP_DMA && NT >= 4) ? 4 * 32 * 1024 : 0;   // lookup staging of the four waves
     // (per launch, not once per process: the attribute is per device, and a cached flag would be unsynchronised global state)
     if (lds_bytes)
         if (hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)) return e;
     const int blocks = lds_bytes ? field_grid_one_per_cu(a.total_tiles) : field_grid(fn, a.total_tiles);
-    hipLaunchKernelGGL((field_tile_kernel<NT, HAS_RES, STORE, DROP, FOLD>), dim3(blocks), dim3(256), lds_bytes, stream, a);
+    hipLaunchKernelGGL((field_tile_kernel<NT, HAS_RES, STORE, DROP, FOLD, WFOLD>), dim3(blocks), dim3(256), lds_bytes, stream, a);
     return hipGetLastError();
 }
 
@@ -1128,6 +1191,7 @@ static hipError_t launch_field_nt(const FieldArgs& a, hipStream_t stream) {
     // a.act_h set: activation-storing forward of the backward pass; a.drop_scale != 0: dropout (training mode)
     if (a.drop_scale != 0.0f)
         return a.act_h ? launch_field_tile<NT, HAS_RES, true, true>(a, stream) : launch_field_tile<NT, HAS_RES, false, true>(a, stream);
+    if (CNERF_F32_WFOLD && !HAS_RES && a.fold && a.packed_img && !a.act_h) return launch_field_tile<NT, false, false, false, true, true>(a, stream);
     if (CNERF_F32_FOLD && a.fold && !a.act_h) return launch_field_tile<NT, HAS_RES, false, false, true>(a, stream);
     return a.act_h ? launch_field_tile<NT, HAS_RES, true, false>(a, stream) : launch_field_tile<NT, HAS_RES, false, false>(a, stream);
 }
