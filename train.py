@@ -33,7 +33,7 @@ def main():
     ap.add_argument("--siren-type", default="SHORTSIREN_FG")
     ap.add_argument("--hidden", type=int, default=256)
     ap.add_argument("--precision", default="fp16x3", choices=["fp32", "fp16x3"],
-                    help="arithmetic of the forward render: fp16x3 = fp32-accurate split products (same 1e-4 parity gate as fp32, 2.6x faster)")
+                    help="arithmetic of the forward render: fp16x3 = fp32-accurate split products (same 1e-4 parity gate as fp32, 2.5x faster)")
     ap.add_argument("--backward-precision", default="fp16", choices=["fp32", "fp16"],
                     help="gradient GEMMs of the render backward: fp16 operands with fp32 sums (gradients within 1e-3 relative L2 of fp32 "
                          "autograd; the reference itself trains under fp16 autocast), or the exact fp32 MFMA chain (3.5x slower)")
