@@ -112,7 +112,7 @@ __device__ __forceinline__ float folded_sine(float pre, float mh, float ml, floa
 #endif
 }
 
-// WFOLD (all-FiLM networks): the scale is folded into the WEIGHTS, per image -- W'_b = diag(freq_b / 2 pi) W, packed per call into the
+// WFOLD (networks without residual blocks): the scale is folded into the WEIGHTS, per image -- W'_b = diag(freq_b / 2 pi) W, packed per call into the
 // workspace (scale_packed_kernel), the accumulator starts from K_b = (freq_b bias + phase_b) / 2 pi -- so the accumulator IS the
 // argument in revolutions and the activation is sin(2 pi (acc - rint(acc))): two vector ops + v_sin, no per-channel constants in the
 // epilogue.  Numerically the sum is rounded at the same relative precision as before; the weights carry one more rounding (6e-8).
