@@ -38,7 +38,13 @@ CHECK_SEED = 4242                                             # torch.cuda seed 
 PMC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE per kernel (scripts/pmc_traffic.sh)
 
 
+def n_matrices(net):
+    from cnerf_amd import ops
+    return ops.n_matrices(net)
+
+
 def macs_per_point(C, H, n_layers):
+    """n_layers = weight matrices before the head (a residual block counts two)."""
     return C * H + (n_layers - 1) * H * H + H * 4             # SHORTSIREN_FG: 205,824 (SURVEY.md 8a)
 
 
@@ -249,7 +255,7 @@ def fast_path(args, gen, fvol, glob, cam, meta, evs, precision="fp16x3"):
     finally:
         gen.siren.precision = "fp32"
     ms = float(np.mean([evs.elapsed_ms(events[4 * i + k], events[4 * i + k + 1]) for i in range(steps) for k in (0, 2)]))
-    flops = 2.0 * macs_per_point(32, args.hidden, len(gen.siren.spec.layers)) * B * R * R * S
+    flops = 2.0 * macs_per_point(32, args.hidden, n_matrices(gen.siren)) * B * R * R * S
     return {"value": B * R * R / dt, "unit": "rays/s", "ms_per_step": dt * 1e3,
             "dtype": "fp16x3 (fp32-equivalent split, fp32 accumulate)" if mfmas == 3 else "fp16 products, fp32 accumulate (tolerance 2e-2, not the 1e-4 gate)",
             "kernel": "field_h3_kernel<8>" if mfmas == 3 else "h1::field_h3_kernel<8> (single pass)", "avg_launch_ms": ms,
@@ -267,7 +273,7 @@ def train_step_timing(args, gen, fvol, glob, cam, evs):
     forward's algorithmic FLOPs (forward + two gradient GEMMs per layer)."""
     B, R, S = args.batch, args.img_size, args.num_steps
     meta = dict(clamp_mode="relu", nerf_noise=1.0, white_back=True, hierarchical_sample=True)
-    flops = 3 * 2 * 2.0 * macs_per_point(32, args.hidden, len(gen.siren.spec.layers)) * B * R * R * S
+    flops = 3 * 2 * 2.0 * macs_per_point(32, args.hidden, n_matrices(gen.siren)) * B * R * R * S
     out = {"images": B, "forward_ms_fp32": None}
     keep = (gen.siren.precision, getattr(gen.siren, "backward_precision", "fp32"))
     gen.train()
@@ -544,7 +550,7 @@ def main():
         e = events[4 * i:4 * i + 4]
         kern_ms += [evs.elapsed_ms(e[0], e[1]), evs.elapsed_ms(e[2], e[3])]
     avg_ms = float(np.mean(kern_ms))
-    n_layers = len(gen.siren.spec.layers)
+    n_layers = n_matrices(gen.siren)
     flops_per_launch = 2.0 * macs_per_point(32, args.hidden, n_layers) * B * R * R * S
     achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
     split = args.precision == "fp16x3"

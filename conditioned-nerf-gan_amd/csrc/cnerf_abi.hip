@@ -496,11 +496,9 @@ int cnerf_render_forward(const cnerf_cfg* cfg, const cnerf_volumes* vols, const 
         if (hipError_t e = launch_fold_film(fa, cfg->B, cfg->H, fold, stream)) return hip_fail(e, "fold_film");
         fa.fold = fold;
         fa.fold_images = cfg->B;
-        bool res = false;
-        for (int l = 0; l < cfg->L; ++l) res |= cfg->layer_kind[l] == CNERF_LAYER_RES;
-        if (!res) {                       // FiLM / plain-sine layers: the scale goes into per-image copies of the layer weights (WFOLD, field_kernel.hip)
+        {                                 // the scale goes into per-image copies of the layer weights (WFOLD, field_kernel.hip)
             const size_t NT = cfg->H / 32;
-            const long long layer_floats = (long long)((NT * pl.n_in + (size_t)(cfg->L - 1) * NT * NT) * 1024);
+            const long long layer_floats = (long long)((NT * pl.n_in + (size_t)(fa.n_mats - 1) * NT * NT) * 1024);
             if (hipError_t e = launch_scale_packed(fa, cfg->B, cfg->H, fold, layer_floats, packed_img, stream)) return hip_fail(e, "scale_packed");
             fa.packed_img = packed_img;
             fa.packed_img_stride = layer_floats;

@@ -112,7 +112,7 @@ __device__ __forceinline__ float folded_sine(float pre, float mh, float ml, floa
 #endif
 }
 
-// WFOLD (networks without residual blocks): the scale is folded into the WEIGHTS, per image -- W'_b = diag(freq_b / 2 pi) W, packed per call into the
+// WFOLD: the scale is folded into the WEIGHTS, per image (a residual matrix adds its block input, scaled by 1 / 2 pi, in the epilogue) -- W'_b = diag(freq_b / 2 pi) W, packed per call into the
 // workspace (scale_packed_kernel), the accumulator starts from K_b = (freq_b bias + phase_b) / 2 pi -- so the accumulator IS the
 // argument in revolutions and the activation is sin(2 pi (acc - rint(acc))): two vector ops + v_sin, no per-channel constants in the
 // epilogue.  Numerically the sum is rounded at the same relative precision as before; the weights carry one more rounding (6e-8).
@@ -197,7 +197,7 @@ __device__ __forceinline__ void mlp_matrix(const f32x4* __restrict__ wp, const f
                 for (int q = 0; q < EPG; ++q) {
                     const int r = (gi / ESTEP) * EPG + q;
                     float cs_ = 0.0f;
-                    if (WFOLD) out[t - 1][r] = wfolded_sine(acc_prev[r]);
+                    if (WFOLD) out[t - 1][r] = wfolded_sine(EPI == EPI_FILM_RES ? __builtin_fmaf(res[t - 1][r], 0.15915494309189535f, acc_prev[r]) : acc_prev[r]);
                     else if (FOLD) out[t - 1][r] = folded_sine(EPI == EPI_FILM_RES ? res[t - 1][r] + acc_prev[r] : acc_prev[r], fr_prev[r], ml_prev[r], ph_prev[r]);
                     else out[t - 1][r] = epilogue_one<EPI, STORE>(acc_prev[r], EPI == EPI_FILM_RES ? res[t - 1][r] : 0.0f, fr_prev[r],
                                                                   ph_prev[r], cs_);
@@ -224,7 +224,7 @@ __device__ __forceinline__ void mlp_matrix(const f32x4* __restrict__ wp, const f
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         float cs_ = 0.0f;
-        if (WFOLD) out[OT - 1][r] = wfolded_sine(acc_prev[r]);
+        if (WFOLD) out[OT - 1][r] = wfolded_sine(EPI == EPI_FILM_RES ? __builtin_fmaf(res[OT - 1][r], 0.15915494309189535f, acc_prev[r]) : acc_prev[r]);
         else if (FOLD) out[OT - 1][r] = folded_sine(EPI == EPI_FILM_RES ? res[OT - 1][r] + acc_prev[r] : acc_prev[r], fr_prev[r], ml_prev[r], ph_prev[r]);
         else out[OT - 1][r] = epilogue_one<EPI, STORE>(acc_prev[r], EPI == EPI_FILM_RES ? res[OT - 1][r] : 0.0f, fr_prev[r], ph_prev[r],
                                                        cs_);
@@ -470,8 +470,8 @@ __global__ __launch_bounds__(256) void field_tile_kernel(FieldArgs a) {
                 STAMP(3);   // hidden layers
             } else {
                 // y = sin(W1 x + b1);  x = sin(x + W2 y + b2)   (tile t of x is dead once its own residual is added)
-                mlp_matrix<NT, NT, EPI_FILM, STORE, false, FOLD>(wp, bias, FOLD ? freq : ones, FOLD ? phase : zeros, x.v, nullptr, y.v, lane, h, row_h,
-                                                                 row_c, nullptr, 0, 0, fml);
+                mlp_matrix<NT, NT, EPI_FILM, STORE, false, FOLD, WFOLD>(wp, bias, FOLD ? freq : ones, FOLD ? phase : zeros, x.v, nullptr, y.v, lane, h,
+                                                                        row_h, row_c, nullptr, 0, 0, fml);
                 if (STORE) {
                     row_h += act_layer;
                     row_c += act_layer;
@@ -483,8 +483,8 @@ __global__ __launch_bounds__(256) void field_tile_kernel(FieldArgs a) {
                     phase += H;
                     fml += H;
                 }
-                mlp_matrix<NT, NT, EPI_FILM_RES, STORE, false, FOLD>(wp, bias, FOLD ? freq : ones, FOLD ? phase : zeros, y.v, x.v, x.v, lane, h, row_h,
-                                                                     row_c, nullptr, 0, 0, fml);
+                mlp_matrix<NT, NT, EPI_FILM_RES, STORE, false, FOLD, WFOLD>(wp, bias, FOLD ? freq : ones, FOLD ? phase : zeros, y.v, x.v, x.v, lane, h,
+                                                                            row_h, row_c, nullptr, 0, 0, fml);
                 if (FOLD) {
                     freq += H;
                     phase += H;
@@ -1191,7 +1191,7 @@ static hipError_t launch_field_nt(const FieldArgs& a, hipStream_t stream) {
     // a.act_h set: activation-storing forward of the backward pass; a.drop_scale != 0: dropout (training mode)
     if (a.drop_scale != 0.0f)
         return a.act_h ? launch_field_tile<NT, HAS_RES, true, true>(a, stream) : launch_field_tile<NT, HAS_RES, false, true>(a, stream);
-    if (CNERF_F32_WFOLD && !HAS_RES && a.fold && a.packed_img && !a.act_h) return launch_field_tile<NT, false, false, false, true, true>(a, stream);
+    if (CNERF_F32_WFOLD && a.fold && a.packed_img && !a.act_h) return launch_field_tile<NT, HAS_RES, false, false, true, true>(a, stream);
     if (CNERF_F32_FOLD && a.fold && !a.act_h) return launch_field_tile<NT, HAS_RES, false, false, true>(a, stream);
     return a.act_h ? launch_field_tile<NT, HAS_RES, true, false>(a, stream) : launch_field_tile<NT, HAS_RES, false, false>(a, stream);
 }
