@@ -258,7 +258,7 @@ int cnerf_workspace_bytes(const cnerf_cfg* cfg, size_t* packed, size_t* fvol_cl,
         // coarse rgb_sigma + z, fine z + rgb_sigma; folded FiLM constants of the call (3 per image, matrix and channel)
         size_t mats = 0;
         for (int l = 0; l < cfg->L; ++l) mats += cfg->layer_kind[l] == CNERF_LAYER_RES ? 2 : 1;
-        // ... 4 per image, matrix and channel; and, for all-FiLM networks in fp32, the row-scaled layer weights per image
+        // ... 4 per image, matrix and channel; and, in fp32, the row-scaled layer weights per image
         const size_t NT = cfg->H / 32;
         const size_t layer_floats = (NT * pl.n_in + (mats - 1) * NT * NT) * 1024;
         *fwd_ws = 2 * align256(N * 4 * sizeof(float)) + 2 * align256(N * sizeof(float)) + align256((size_t)4 * cfg->B * mats * cfg->H * sizeof(float)) +

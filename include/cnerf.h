@@ -193,7 +193,8 @@ const char* cnerf_last_error(void);
  *   packed   : packed field weights written by cnerf_pack_field
  *   fvol_cl  : channel-last copy of the feature volume written by cnerf_fvol_channel_last
  *   fwd_ws   : scratch of cnerf_render_forward (coarse / fine rgb_sigma and depths, and the folded FiLM constants of the call:
- *              per image, matrix and channel  freq / 2 pi  and  phase / 2 pi, prepared once for both field passes in fp32 precision) */
+ *              per image, matrix and channel  freq / 2 pi  and  (freq * bias + phase) / 2 pi, and the layer weights with their rows scaled
+ *              by freq / 2 pi per image, prepared once for both field passes in fp32 precision) */
 int cnerf_workspace_bytes(const cnerf_cfg* cfg, size_t* packed, size_t* fvol_cl, size_t* fwd_ws);
 
 /* (B,C,V,V,V) channel-first, as unet3d emits it (generators/unet3d.py) -> (B,V,V,V,C) channel-last, so that one
