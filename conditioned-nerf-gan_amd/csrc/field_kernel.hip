@@ -114,12 +114,22 @@ __device__ __forceinline__ float folded_sine(float pre, float mh, float ml, floa
 
 // WFOLD: the scale is folded into the WEIGHTS, per image (a residual matrix adds its block input, scaled by 1 / 2 pi, in the epilogue) -- W'_b = diag(freq_b / 2 pi) W, packed per call into the
 // workspace (scale_packed_kernel), the accumulator starts from K_b = (freq_b bias + phase_b) / 2 pi -- so the accumulator IS the
-// argument in revolutions and the activation is sin(2 pi (acc - rint(acc))): two vector ops + v_sin, no per-channel constants in the
+// argument in revolutions and the activation is sin(2 pi fract(acc)): one vector op + v_sin, no per-channel constants in the
 // epilogue.  Numerically the sum is rounded at the same relative precision as before; the weights carry one more rounding (6e-8).
 #ifndef CNERF_F32_WFOLD
 #define CNERF_F32_WFOLD 1
 #endif
-__device__ __forceinline__ float wfolded_sine(float u) { return __builtin_amdgcn_sinf(u - __builtin_rintf(u)); }
+#ifndef CNERF_F32_WFOLD_REDUCE
+// Reduction of the accumulator (revolutions) in front of v_sin_f32, which is specified for |u| <= 256 only:
+//   2: v_fract_f32 -- one vector op, any magnitude; [0, 1) instead of [-0.5, 0.5] costs half an ulp of 1 on the argument: <= 3.1e-7 abs
+//   1: u - rint(u) -- two vector ops, exact, 1.2e-7
+//   0: none -- 1.2e-7 as well for |u| <= 250 (the unit reduces by itself) but 0 beyond 256 revolutions: measurement only
+// scripts/ab_wfold_raw.sh, scripts/ubench/vsin_raw_range.hip
+#define CNERF_F32_WFOLD_REDUCE 2
+#endif
+__device__ __forceinline__ float wfolded_sine(float u) {
+    return __builtin_amdgcn_sinf(CNERF_F32_WFOLD_REDUCE == 2 ? __builtin_amdgcn_fractf(u) : CNERF_F32_WFOLD_REDUCE == 1 ? u - __builtin_rintf(u) : u);
+}
 
 template <int EPI, bool STORE>
 __device__ __forceinline__ float epilogue_one(float acc, float res, float fr, float ph, float& cs) {
