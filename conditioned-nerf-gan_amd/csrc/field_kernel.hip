@@ -119,16 +119,21 @@ __device__ __forceinline__ float folded_sine(float pre, float mh, float ml, floa
 #ifndef CNERF_F32_WFOLD
 #define CNERF_F32_WFOLD 1
 #endif
+// Reduction of the accumulator (revolutions) in front of v_sin_f32, which is specified for |u| <= 256 only -- the WFOLD template
+// argument of the kernels (0 = no weight folding):
+//   1: v_fract_f32 -- one vector op, any magnitude; [0, 1) instead of [-0.5, 0.5] costs half an ulp of 1 on a negative argument
+//      (<= 2.7e-7 abs instead of 1.2e-7).  Networks with FiLM layers (arguments of tens of radians: ulp 4e-6 and more).
+//   2: u - rint(u) -- two vector ops, exact, 1.2e-7.  Networks of plain sine layers / residual blocks, whose hidden arguments are
+//      a few radians: there the half ulp of `fract` is visible (sigma of tests/golden/short_f_small 1.6e-5 -> 6.3e-5 of its scale).
+// (v_sin_f32 alone also reduces by itself, 1.2e-7 for |u| <= 250, but returns 0 beyond 256 revolutions: measurement only,
+// -DCNERF_F32_WFOLD_REDUCE=0.)  scripts/ab_wfold_raw.sh, scripts/ubench/vsin_raw_range.hip, profiles/r02_vsin_reduction.txt
 #ifndef CNERF_F32_WFOLD_REDUCE
-// Reduction of the accumulator (revolutions) in front of v_sin_f32, which is specified for |u| <= 256 only:
-//   2: v_fract_f32 -- one vector op, any magnitude; [0, 1) instead of [-0.5, 0.5] costs half an ulp of 1 on the argument: <= 3.1e-7 abs
-//   1: u - rint(u) -- two vector ops, exact, 1.2e-7
-//   0: none -- 1.2e-7 as well for |u| <= 250 (the unit reduces by itself) but 0 beyond 256 revolutions: measurement only
-// scripts/ab_wfold_raw.sh, scripts/ubench/vsin_raw_range.hip
-#define CNERF_F32_WFOLD_REDUCE 2
+#define CNERF_F32_WFOLD_REDUCE (-1)    // -1: as the kernel's WFOLD argument says; 0 / 1 / 2: none / fract / rint everywhere (experiments)
 #endif
+template <int WFOLD>
 __device__ __forceinline__ float wfolded_sine(float u) {
-    return __builtin_amdgcn_sinf(CNERF_F32_WFOLD_REDUCE == 2 ? __builtin_amdgcn_fractf(u) : CNERF_F32_WFOLD_REDUCE == 1 ? u - __builtin_rintf(u) : u);
+    constexpr int mode = CNERF_F32_WFOLD_REDUCE >= 0 ? CNERF_F32_WFOLD_REDUCE : WFOLD;
+    return __builtin_amdgcn_sinf(mode == 1 ? __builtin_amdgcn_fractf(u) : mode == 2 ? u - __builtin_rintf(u) : u);
 }
 
 template <int EPI, bool STORE>
@@ -166,7 +171,7 @@ __device__ __forceinline__ void store_tile_rows(float* __restrict__ row /* &buf[
 // full 2 cycles whether spread between the MFMAs or clumped, with one or two accumulator chains -- so for the fp32
 // path  time = MFMA + VALU + stalls  and the epilogue placement only matters for register pressure and load distance.
 // DROP: the finished tile (and its cosine row) is multiplied by the dropout factors of layer `drop_d` at point `drop_gp`.
-template <int OT, int KT, int EPI, bool STORE, bool DROP = false, bool FOLD = false, bool WFOLD = false>
+template <int OT, int KT, int EPI, bool STORE, bool DROP = false, bool FOLD = false, int WFOLD = 0>
 __device__ __forceinline__ void mlp_matrix(const f32x4* __restrict__ wp, const float* __restrict__ bias,
                                            const float* __restrict__ freq, const float* __restrict__ phase,
                                            const f32x16* in, const f32x16* res, f32x16* out, int lane, int h,
@@ -207,7 +212,7 @@ __device__ __forceinline__ void mlp_matrix(const f32x4* __restrict__ wp, const f
                 for (int q = 0; q < EPG; ++q) {
                     const int r = (gi / ESTEP) * EPG + q;
                     float cs_ = 0.0f;
-                    if (WFOLD) out[t - 1][r] = wfolded_sine(EPI == EPI_FILM_RES ? __builtin_fmaf(res[t - 1][r], 0.15915494309189535f, acc_prev[r]) : acc_prev[r]);
+                    if (WFOLD) out[t - 1][r] = wfolded_sine<WFOLD>(EPI == EPI_FILM_RES ? __builtin_fmaf(res[t - 1][r], 0.15915494309189535f, acc_prev[r]) : acc_prev[r]);
                     else if (FOLD) out[t - 1][r] = folded_sine(EPI == EPI_FILM_RES ? res[t - 1][r] + acc_prev[r] : acc_prev[r], fr_prev[r], ml_prev[r], ph_prev[r]);
                     else out[t - 1][r] = epilogue_one<EPI, STORE>(acc_prev[r], EPI == EPI_FILM_RES ? res[t - 1][r] : 0.0f, fr_prev[r],
                                                                   ph_prev[r], cs_);
@@ -234,7 +239,7 @@ __device__ __forceinline__ void mlp_matrix(const f32x4* __restrict__ wp, const f
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         float cs_ = 0.0f;
-        if (WFOLD) out[OT - 1][r] = wfolded_sine(EPI == EPI_FILM_RES ? __builtin_fmaf(res[OT - 1][r], 0.15915494309189535f, acc_prev[r]) : acc_prev[r]);
+        if (WFOLD) out[OT - 1][r] = wfolded_sine<WFOLD>(EPI == EPI_FILM_RES ? __builtin_fmaf(res[OT - 1][r], 0.15915494309189535f, acc_prev[r]) : acc_prev[r]);
         else if (FOLD) out[OT - 1][r] = folded_sine(EPI == EPI_FILM_RES ? res[OT - 1][r] + acc_prev[r] : acc_prev[r], fr_prev[r], ml_prev[r], ph_prev[r]);
         else out[OT - 1][r] = epilogue_one<EPI, STORE>(acc_prev[r], EPI == EPI_FILM_RES ? res[OT - 1][r] : 0.0f, fr_prev[r], ph_prev[r],
                                                        cs_);
@@ -273,7 +278,7 @@ __device__ __forceinline__ void layer0_accumulate(const f32x4* __restrict__ wp, 
 }
 
 // x[t] = sin(freq * y[t] + phase) for all tiles (+ activation store)
-template <int NT, bool STORE, bool DROP = false, bool FOLD = false, bool WFOLD = false>
+template <int NT, bool STORE, bool DROP = false, bool FOLD = false, int WFOLD = 0>
 __device__ __forceinline__ void film_all(const f32x16* y, f32x16* x, const float* __restrict__ freq,
                                          const float* __restrict__ phase, int h, float* row_h, float* row_c,
                                          const FieldArgs* da = nullptr, unsigned long long drop_gp = 0,
@@ -293,7 +298,7 @@ __device__ __forceinline__ void film_all(const f32x16* y, f32x16* x, const float
         f32x16 o, cs;
         if (WFOLD) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[r] = wfolded_sine(y[t][r]);
+            for (int r = 0; r < 16; ++r) o[r] = wfolded_sine<WFOLD>(y[t][r]);
         } else if (FOLD) {
             const f32x16 ml = load_chan16(fold_ml, t, h);
 #pragma unroll
@@ -347,7 +352,7 @@ __device__ __forceinline__ void film_all(const f32x16* y, f32x16* x, const float
 #define CNERF_F32_LOOKUP_DMA 0
 #endif
 
-template <int NT, bool HAS_RES, bool STORE, bool DROP, bool FOLD = false, bool WFOLD = false>
+template <int NT, bool HAS_RES, bool STORE, bool DROP, bool FOLD = false, int WFOLD = 0>
 __global__ __launch_bounds__(256) void field_tile_kernel(FieldArgs a) {
 #ifdef CNERF_STAMPS
     unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1183,7 +1188,7 @@ hipError_t launch_field_backward(const FieldArgs& a, int H, hipStream_t stream) 
     }
 }
 
-template <int NT, bool HAS_RES, bool STORE, bool DROP, bool FOLD = false, bool WFOLD = false>
+template <int NT, bool HAS_RES, bool STORE, bool DROP, bool FOLD = false, int WFOLD = 0>
 static hipError_t launch_field_tile(const FieldArgs& a, hipStream_t stream) {
     if (a.n_in < 1 || a.in_level[0] < 0) return hipErrorInvalidValue;      // the lookup prefetch assumes a volume tile first
     const void* fn = (const void*)field_tile_kernel<NT, HAS_RES, STORE, DROP, FOLD, WFOLD>;
@@ -1201,7 +1206,10 @@ static hipError_t launch_field_nt(const FieldArgs& a, hipStream_t stream) {
     // a.act_h set: activation-storing forward of the backward pass; a.drop_scale != 0: dropout (training mode)
     if (a.drop_scale != 0.0f)
         return a.act_h ? launch_field_tile<NT, HAS_RES, true, true>(a, stream) : launch_field_tile<NT, HAS_RES, false, true>(a, stream);
-    if (CNERF_F32_WFOLD && a.fold && a.packed_img && !a.act_h) return launch_field_tile<NT, HAS_RES, false, false, true, true>(a, stream);
+    if (CNERF_F32_WFOLD && a.fold && a.packed_img && !a.act_h) {      // (which reduction in front of v_sin: wfolded_sine above)
+        if constexpr (HAS_RES) return launch_field_tile<NT, true, false, false, true, 2>(a, stream);
+        else return a.freq ? launch_field_tile<NT, false, false, false, true, 1>(a, stream) : launch_field_tile<NT, false, false, false, true, 2>(a, stream);
+    }
     if (CNERF_F32_FOLD && a.fold && !a.act_h) return launch_field_tile<NT, HAS_RES, false, false, true>(a, stream);
     return a.act_h ? launch_field_tile<NT, HAS_RES, true, false>(a, stream) : launch_field_tile<NT, HAS_RES, false, false>(a, stream);
 }
