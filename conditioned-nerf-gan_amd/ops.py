@@ -337,6 +337,8 @@ def pack_field_transposed(net, cfg):
 
 
 DEBUG_CAPTURE = None            # set to a dict to capture the backward's chunk buffers (scripts/debug_b16.py)
+PHASE_TIMER = None              # an object with begin() / end(name, start) (training.gan_step.PhaseTimer): RenderFunction.backward
+                                # reports its span as "render_bwd" so that a caller can split an autograd pass (bench.py gan_step)
 ACT_BUDGET_BYTES = 128 << 30    # activation / gradient chunk buffers of the backward (288 GB HBM per GPU: batch 8 at 128x128x64 in one chunk)
 
 
@@ -750,12 +752,15 @@ class RenderFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_pixels, grad_depth):
         levels, fr, ph, cam2world, saved = ctx.saved
+        t0 = PHASE_TIMER.begin() if PHASE_TIMER is not None else None
         g_levels, g_freq, g_phase, g_params = render_backward(ctx.net, ctx.o, levels, fr, ph, cam2world, ctx.rng, saved,
                                                               grad_pixels.contiguous(),
                                                               grad_depth.contiguous() if grad_depth is not None else None,
                                                               act16=ctx.act16)
         ctx.act16 = None
         g_vols = [g.permute(0, 4, 1, 2, 3) if cl else channel_first(g) for g, cl in zip(g_levels, ctx.vol_is_cl)]
+        if t0 is not None:
+            PHASE_TIMER.end("render_bwd", t0)
         return (None, None, None, None, g_freq, g_phase, None, *g_vols, *g_params)
 
 

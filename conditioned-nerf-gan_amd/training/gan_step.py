@@ -13,10 +13,63 @@ import torch
 import torch.nn.functional as F
 from torch.nn.parallel import DistributedDataParallel as DDP
 
+import time
+
 from ..generators import ImplicitGenerator3d
 from ..generators.volumetric_rendering import create_cam2world_matrix, sample_camera_positions
 from . import discriminator as discriminators
 from .encoder import UNet3D
+
+
+class PhaseTimer:
+    """Wall time of the phases of a GAN step: event pairs on the current stream of a GPU (torch's stream is the one every kernel of
+    the step -- MIOpen, rocBLAS, the render path through the C ABI -- is launched on), perf_counter on the CPU.  Nothing is
+    synchronised while a step runs; summary() waits once and adds up the occurrences of each phase name."""
+
+    def __init__(self, device):
+        self.cuda = torch.device(device).type == "cuda"
+        self.spans = []
+
+    def begin(self):
+        if self.cuda:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            return ev
+        return time.perf_counter()
+
+    def end(self, name, start):
+        self.spans.append((name, start, self.begin()))
+
+    def summary(self):
+        if self.cuda:
+            torch.cuda.synchronize()
+        out = {}
+        for name, a, b in self.spans:
+            out[name] = out.get(name, 0.0) + (a.elapsed_time(b) if self.cuda else (b - a) * 1e3)
+        self.spans = []
+        return out
+
+
+class CommMeter:
+    """Communication hook of a DDP wrapper that counts what it sends: all-reduce calls (= gradient buckets) and bytes, and how
+    often the LAST bucket went out (= all-reduce rounds: one per backward that synchronises).  The reduction itself is DDP's
+    default (average over the process group: RCCL on a GPU job, gloo in the CPU tests)."""
+
+    def __init__(self):
+        self.calls = self.bytes = self.rounds = 0
+
+    def hook(self, state, bucket):
+        from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
+        buf = bucket.buffer()
+        self.calls += 1
+        self.bytes += buf.numel() * buf.element_size()
+        self.rounds += 1 if bucket.is_last() else 0
+        return default_hooks.allreduce_hook(state, bucket)
+
+    def take(self):
+        out = {"calls": self.calls, "bytes": self.bytes, "rounds": self.rounds}
+        self.calls = self.bytes = self.rounds = 0
+        return out
 
 
 def default_metadata(img_size=128, num_steps=64, batch_size=8, batch_split=4, siren_type="SHORTSIREN_FG", hidden_dim=256):
@@ -81,9 +134,37 @@ class GanTrainer:
         self._z = {}            # chunk index -> encoder output kept between the D and the G pass of one step
         self.last = {}          # diagnostics of the most recent step: loss terms and pre-clip gradient norms
         self.render_rng = None  # test hook: callable(chunk_index, phase) -> dict of injected draws for that render
+        self.timer = None       # a PhaseTimer while a caller wants the step split into phases (bench.py), else None
+        self.comm = {}          # name -> CommMeter once attach_comm_meters() ran (DDP only)
 
-    def _disc(self, imgs):
-        out = self.discriminator_ddp(imgs, self.alpha, **self.metadata)
+    def attach_comm_meters(self):
+        """Counts the all-reduces of the three DDP wrappers from here on (bench.py, tests); {} without DDP."""
+        if self.ddp and not self.comm:
+            for name, m in (("generator", self.generator_ddp), ("encoder", self.encoder_ddp), ("discriminator", self.discriminator_ddp)):
+                self.comm[name] = CommMeter()
+                m.register_comm_hook(None, self.comm[name].hook)
+        return self.comm
+
+    @contextlib.contextmanager
+    def _phase(self, name):
+        if self.timer is None:
+            yield
+            return
+        t0 = self.timer.begin()
+        try:
+            yield
+        finally:
+            self.timer.end(name, t0)
+
+    def _disc(self, imgs, frozen=False):
+        """frozen: the G step's use of the discriminator -- only d(prediction)/d(images) is needed there (the reference lets the
+        backward fill the discriminator's parameter gradients too and zeroes them afterwards, utils.py:665-741).  The raw module
+        runs with its parameters' requires_grad off: no weight-gradient kernels, and under DDP no all-reduce of 47 MiB of
+        gradients nobody reads.  Same images' gradients, same step."""
+        if frozen:
+            out = self.discriminator(imgs, self.alpha, **self.metadata)
+        else:
+            out = self.discriminator_ddp(imgs, self.alpha, **self.metadata)
         return out[0] if isinstance(out, tuple) else out       # (CCSDiscriminator returns (prediction, None, None))
 
     # utils.py:610-618
@@ -125,7 +206,9 @@ class GanTrainer:
                 cams = create_cam2world_matrix(sample_camera_positions(self.device, "y", md["cam_r_start"], md["cam_r_end"], n), "y", self.device)
             else:
                 cams = sample["cam2world"].to(self.device)
-            fake = torch.cat([self._render(voxels[c], cams[c], i, "d")[0] for i, c in enumerate(self._chunks(n))], 0)
+            with self._phase("d_render"):
+                fake = torch.cat([self._render(voxels[c], cams[c], i, "d")[0] for i, c in enumerate(self._chunks(n))], 0)
+        t_d = self.timer.begin() if self.timer is not None else None
         r_preds = self._disc(real)
         penalty = 0.0
         if md["r1_lambda"] > 0:
@@ -137,6 +220,8 @@ class GanTrainer:
         d_loss.backward()
         gn = torch.nn.utils.clip_grad_norm_(self.discriminator_ddp.parameters(), md["grad_clip"])
         self.optimizer_D.step()
+        if t_d is not None:
+            self.timer.end("d_disc_r1_opt", t_d)
         self.losses["d"].append(d_loss.item())
         self.last.update(d_loss=d_loss.item(), r1_penalty=float(penalty.detach()) if torch.is_tensor(penalty) else float(penalty), d_grad_norm=float(gn), fake_mean=float(fake.mean()))
 
@@ -146,27 +231,37 @@ class GanTrainer:
         imgs, cams, voxels = (sample[k].to(self.device) for k in ("img", "cam2world", "voxel"))
         chunks = self._chunks(imgs.shape[0])
         g_acc = p_acc = 0.0
-        for i, c in enumerate(chunks):
-            last = i == len(chunks) - 1
-            ctx = contextlib.ExitStack()
-            if self.ddp and not last:       # one all-reduce per optimizer step, not one per chunk
-                for m in (self.generator_ddp, self.encoder_ddp, self.discriminator_ddp):
-                    ctx.enter_context(m.no_sync())
-            with ctx:
-                gen_imgs, _ = self._render(voxels[c], cams[c], i, "g")
-                if md["enable_discriminator"]:
-                    loss_g = F.softplus(-self._disc(gen_imgs)).mean()
-                else:
-                    loss_g = gen_imgs.new_zeros(())
-                photo = F.mse_loss(gen_imgs, imgs[c]) if md["photo_loss"] else gen_imgs.new_zeros(())
-                (loss_g + photo).backward()
-            g_acc += loss_g.item()
-            p_acc += photo.item()
-        for name, model, opt in (("g", self.generator_ddp, self.optimizer_G), ("e", self.encoder_ddp, self.optimizer_E)):
-            self.last[name + "_grad_norm"] = float(torch.nn.utils.clip_grad_norm_(model.parameters(), md.get("grad_clip", 0.3)))
-            opt.step()
-            opt.zero_grad()
-        self.optimizer_D.zero_grad()        # the G step also left gradients in the discriminator
+        d_params = [p for p in self.discriminator.parameters() if p.requires_grad]
+        for p in d_params:                  # see _disc(frozen=True)
+            p.requires_grad_(False)
+        try:
+            for i, c in enumerate(chunks):
+                last = i == len(chunks) - 1
+                ctx = contextlib.ExitStack()
+                if self.ddp and not last:       # one all-reduce per optimizer step, not one per chunk
+                    for m in (self.generator_ddp, self.encoder_ddp):
+                        ctx.enter_context(m.no_sync())
+                with ctx:
+                    with self._phase("g_render_fwd" if i in self._z else "g_encoder_render_fwd"):
+                        gen_imgs, _ = self._render(voxels[c], cams[c], i, "g")
+                    with self._phase("g_disc_loss_fwd"):
+                        if md["enable_discriminator"]:
+                            loss_g = F.softplus(-self._disc(gen_imgs, frozen=True)).mean()
+                        else:
+                            loss_g = gen_imgs.new_zeros(())
+                        photo = F.mse_loss(gen_imgs, imgs[c]) if md["photo_loss"] else gen_imgs.new_zeros(())
+                    with self._phase("g_backward"):
+                        (loss_g + photo).backward()
+                g_acc += loss_g.item()
+                p_acc += photo.item()
+        finally:
+            for p in d_params:
+                p.requires_grad_(True)
+        with self._phase("g_clip_opt"):
+            for name, model, opt in (("g", self.generator_ddp, self.optimizer_G), ("e", self.encoder_ddp, self.optimizer_E)):
+                self.last[name + "_grad_norm"] = float(torch.nn.utils.clip_grad_norm_(model.parameters(), md.get("grad_clip", 0.3)))
+                opt.step()
+                opt.zero_grad()
         self.losses["g"].append(g_acc / len(chunks))
         self.losses["photo"].append(p_acc / len(chunks))
         self.last.update(g_loss=g_acc / len(chunks), photo_loss=p_acc / len(chunks))
@@ -209,7 +304,7 @@ class GanTrainer:
                 last = i == len(chunks) - 1
                 if self.ddp and last and len(chunks) > 1:
                     continue                 # (a single chunk is fine: no other encoder backward sits between its forward and its own)
-                with (self.encoder_ddp.no_sync() if self.ddp and not last else contextlib.nullcontext()):
+                with (self.encoder_ddp.no_sync() if self.ddp and not last else contextlib.nullcontext()), self._phase("encoder_fwd"):
                     self._z[i] = self._encode(voxels[c])
         if self.metadata["enable_discriminator"]:
             self.train_discriminator(sample)

@@ -70,6 +70,7 @@ def test_bench_launches_its_own_ranks():
     import json
     import subprocess
     import sys
+    import numpy as np
     from conftest import ROOT
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--device", "cpu"],
@@ -82,6 +83,18 @@ def test_bench_launches_its_own_ranks():
     assert res["ms_per_step"] >= 10.0 * 0.9                  # the slower rank (rank 1: 10 ms per step) sets the time
     assert abs(res["value"] - 2 * 8 * 128 * 128 / (res["ms_per_step"] * 1e-3)) < 1e-6 * res["value"]
     assert "stub" in res["data"]
+    # the DDP training leg (gloo here, RCCL on the GPU box): the real GanTrainer around a stand-in generator, three DDP wrappers
+    ddp = res["train_step_ddp"]
+    assert ddp["n_ranks"] == 2 and ddp["backend"] == "gloo"
+    ar = ddp["allreduce_per_optimizer_step"]
+    assert set(ar) == {"generator", "encoder", "discriminator"}
+    for name, c in ar.items():                               # ONE all-reduce round per optimizer step and network ...
+        assert c["rounds"] == 1.0 and c["calls"] >= 1.0, (name, c)
+        assert c["bytes"] == 4 * ddp["parameters"][name], (name, c)      # ... carrying every fp32 gradient exactly once
+    assert ddp["allreduce_bytes_per_step"] == sum(c["bytes"] for c in ar.values())
+    assert set(ddp["allreduce_standalone"]) == set(ar) and all(v["ms"] > 0 for v in ddp["allreduce_standalone"].values())
+    assert {"d_render", "d_disc_r1_opt", "g_render_fwd", "g_backward", "g_clip_opt", "encoder_fwd"} <= set(ddp["phases_ms_rank0"])
+    assert all(np.isfinite(v) for v in ddp["losses"].values())
 
 
 def test_bench_launcher_propagates_failure():
@@ -217,3 +230,53 @@ def test_keeping_the_encoder_output_between_the_d_and_g_pass_changes_nothing(bat
             tr.step(sample)
         out.append(torch.cat([p.detach().flatten() for m in (tr.generator, tr.encoder, tr.discriminator) for p in m.parameters()]))
     assert torch.allclose(out[0], out[1], rtol=0, atol=1e-7)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# rank-0-first start-up work must not be waited for inside a collective (the MIOpen search on rank 0 takes up to 8 minutes,
+# the default watchdog of the process group is 10)
+# ---------------------------------------------------------------------------------------------------------------------
+def _latch_worker(rank, world, port, q, use_latch, tmp):
+    import datetime
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=3))
+    import cnerf_amd  # noqa: F401
+    from cnerf_amd.training.latch import rank0_first
+    slow = lambda: time.sleep(7.0)                           # rank 0's start-up work outlasts the group's timeout
+    ok = True
+    try:
+        if use_latch:
+            rank0_first(rank, "slow", slow, tmp)             # train.py's scheme: the others poll a marker file ...
+            dist.barrier()                                   # ... and the collective that follows is entered by all ranks together
+        else:
+            if rank == 0:
+                slow()
+            dist.barrier()                                   # the round-2 scheme: rank 1 waits 7 s inside a 3-s collective
+    except Exception:                                        # noqa: BLE001  (gloo raises a RuntimeError / DistBackendError on timeout)
+        ok = False
+    q.put((rank, ok))
+    try:
+        dist.destroy_process_group()
+    except Exception:                                        # noqa: BLE001
+        pass
+
+
+@pytest.mark.timeout(180)
+def test_rank0_first_work_outlasting_the_group_timeout(tmp_path):
+    """A marker-file latch (training/latch.py) lets rank 0 work for longer than the process group's timeout while the other ranks
+    wait; the same wait inside a barrier aborts (which is what train.py's start-up did at 72-80 % of NCCL's 10 minutes)."""
+    ctx = mp.get_context("spawn")
+    for use_latch, want in ((True, True), (False, False)):
+        port, q = _free_port(), ctx.Queue()
+        procs = [ctx.Process(target=_latch_worker, args=(r, 2, port, q, use_latch, str(tmp_path))) for r in range(2)]
+        for p in procs:
+            p.start()
+        res = dict(q.get(timeout=90) for _ in range(2))
+        for p in procs:
+            p.join(30)
+            if p.is_alive():
+                p.kill()
+        if want:
+            assert res == {0: True, 1: True}
+        else:
+            assert not res[1]                                # the waiting rank's collective timed out

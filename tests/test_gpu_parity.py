@@ -631,7 +631,7 @@ def _oracle_case(dev, variant, B, R, S, V, H, clamp="relu", noise=0.0, white=Tru
     import cnerf_amd
     from cnerf_amd.generators import ImplicitGenerator3d
     from cnerf_amd.generators.volumetric_rendering import sample_camera_positions, create_cam2world_matrix
-    from oracle import render_oracle as O
+    from oracle import render_oracle as O, checks as K
     torch.manual_seed(seed)
     np.random.seed(seed)
     has_glob = O.FIELD_SPECS[variant].has_global
@@ -652,6 +652,10 @@ def _oracle_case(dev, variant, B, R, S, V, H, clamp="relu", noise=0.0, white=Tru
     r = {k: v.to(dev) for k, v in rng.items()}
     r["fine_z"] = ref.aux["fine_z"].to(dev)
     z = (fvol.to(dev), glob.to(dev)) if has_glob else fvol.to(dev)
+    # the field in float64 at (a strided sample of at most ~1 M of) the coarse sample positions: the yardstick of accuracy_vs_fp64
+    npi = P * S
+    sub = torch.arange(0, npi, max(1, (B * npi + (1 << 20) - 1) >> 20))
+    exact = K.field_fp64(variant, params, fvol, glob, ref.aux["coarse_points"].reshape(B, npi, 3)[:, sub])
     out = {}
     for prec in ((precision,) if isinstance(precision, str) else precision):
         gen.siren.precision = prec
@@ -667,20 +671,25 @@ def _oracle_case(dev, variant, B, R, S, V, H, clamp="relu", noise=0.0, white=Tru
         assert e_c < TOL and e_f < TOL, (prec, e_c, e_f)
         same = (aux["inds"].cpu() == ref.aux["inds"]).float().mean().item()
         assert same > 0.99, (prec, same)
+        # "as accurate as the reference" measured: both fp32 results against the field in float64 at the same positions
+        acc = K.accuracy_vs_fp64(aux["coarse_rgb_sigma"].cpu().reshape(B, -1, 4)[:, sub], ref.aux["coarse_rgb_sigma"].reshape(B, -1, 4)[:, sub], exact)
+        if B * npi >= 4096:      # (a maximum over a handful of points is no statistic: recorded, not asserted)
+            assert acc["hip_vs_fp64"] <= 2 * acc["ref_vs_fp64"] + 1e-6, (prec, acc)
         if P > 1:      # (a single ray has no rms to scale by)
-            px_c, dp_c, px_r, dp_r = px.cpu().clone(), dp.cpu().clone(), ref.pixels.clone(), ref.depth.clone()
-            edge = knife_edge_rays(ref.aux, clamp)
-            if edge is not None and edge.any():        # rays the reference itself is discontinuous on: take the reference's value
+            # rays the reference itself is discontinuous on (last-sample density at a zero crossing under relu): the HIP value must
+            # equal ONE of the reference algorithm's two branches there -- a positive check, nothing is left out of the maximum
+            edge = K.knife_edge_rays(ref.aux, clamp)
+            branches = None
+            if edge is not None and edge.any():
                 assert edge.float().mean().item() < 1e-3, edge.float().mean().item()
-                m = edge.reshape(B, R, R)
-                px_c = torch.where(m.unsqueeze(1), px_r, px_c)
-                dp_c = torch.where(m, dp_r, dp_c)
-            e_p, e_d = scaled_err(px_c.numpy(), px_r.numpy()), scaled_err(dp_c.numpy(), dp_r.numpy())
-            assert e_p < 2 * TOL and e_d < 2 * TOL, (prec, e_p, e_d)
+                branches = K.knife_edge_branches(ref.aux, R, 49.13, noise, white, last, rng["eps_final"])
+            e_p, e_d, n_edge = K.image_err_with_knife_edges(px, dp, ref.pixels, ref.depth, edge, branches)
+            assert e_p < 2 * TOL and e_d < 2 * TOL, (prec, e_p, e_d, n_edge)
         else:
             e_p = e_d = np.abs(px.cpu().numpy() - ref.pixels.numpy()).max()
+            n_edge = 0
             assert e_p < 2e-4
-        out[prec] = dict(coarse=e_c, fine=e_f, inds_same=same, pixels=e_p, depth=e_d,
+        out[prec] = dict(coarse=e_c, fine=e_f, inds_same=same, pixels=e_p, depth=e_d, knife_edge_rays=n_edge, **acc,
                          survey_rs=survey_metric_pass(aux["coarse_rgb_sigma"].cpu().numpy(), ref.aux["coarse_rgb_sigma"].numpy()),
                          survey_px=survey_metric_pass(px.cpu().numpy(), ref.pixels.numpy()))
     return out
@@ -692,20 +701,6 @@ def rgb_sigma_err(a, b):
     a = a.cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
     b = b.cpu().numpy() if torch.is_tensor(b) else np.asarray(b)
     return max(scaled_err(a[..., :3], b[..., :3]), scaled_err(a[..., 3], b[..., 3]))
-
-
-def knife_edge_rays(ref_aux, clamp, tol=TOL):
-    """Rays on which the REFERENCE's image is discontinuous in its own densities: the last merged sample of a ray is composited with
-    delta = 1e10 (volumetric_rendering.py:30-33), so under the relu clamp its alpha is 0 for sigma <= 0 and 1 for any sigma > 0 --
-    a density within the rgb / sigma tolerance of zero there can flip the whole remaining transmittance of the ray.  Returns the
-    mask (B, P) of rays whose last sample's reference density lies inside the admissible band |sigma| <= tol * rms(sigma); their
-    pixels are excluded from the image comparison (a handful per 65 k rays; every other ray must agree).  softplus is continuous."""
-    if clamp != "relu":
-        return None
-    f, c = ref_aux.get("fine_rgb_sigma"), ref_aux["coarse_rgb_sigma"]
-    sig = torch.cat([f[..., 3], c[..., 3]], -1) if f is not None else c[..., 3]
-    last = torch.gather(sig, -1, ref_aux["sort_idx"][..., -1:].long())[..., 0] if f is not None else sig[..., -1]
-    return last.abs() <= tol * float(sig.square().mean().sqrt())
 
 
 def merge_order_matches(sort_idx, ref_sort_idx, fine_z, coarse_z):
@@ -736,6 +731,10 @@ def test_benchmarked_shape_matches_oracle(dev):
     bit-exact, rgb / sigma of both passes within 1e-4, image within 2e-4 (fine depths forced, as everywhere)."""
     res = _oracle_case(dev, "SHORTSIREN_FG", B=2, R=128, S=64, V=64, H=256, Z=256, precision=("fp32", "fp16x3"), seed=11)
     print("benchmarked shape:", res)
+    # margin guard: the gate is 1e-4; a kernel change that eats the rest of the margin at the benchmarked shape fails HERE, loudly,
+    # before it can flip a fixture (round 2 spent the margin from 2e-5 to 7e-5 on the folded epilogue: VERDICT r02 weak #1)
+    for prec, r in res.items():
+        assert max(r["coarse"], r["fine"]) < 0.9e-4, (prec, r)
 
 
 def test_config5_shape_matches_oracle(dev):

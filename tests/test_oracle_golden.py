@@ -138,3 +138,60 @@ def test_importance_depths_edges():
     inside = (fine >= mids[..., 2] - 1e-6) & (fine <= mids[..., 3] + 1e-6)
     assert inside[..., 1:-1].all()
     assert abs(cdf[..., -1].item() - 1) < 1e-6
+
+
+RELU_HIER = [n for n in SMALL_GOLDEN if n not in ("short_fg_nohier",)]
+
+
+@pytest.mark.parametrize("name", RELU_HIER)
+def test_knife_edge_branches_contain_the_reference(golden, name):
+    """oracle/checks.py::knife_edge_branches (the positive check that replaced the exclusion of rays at a density zero crossing):
+    under the relu clamp every ray of the reference's own image equals ONE of the two branch images -- last-sample alpha forced
+    to 0 / to 1 -- bit for bit, the branch being the sign of that sample's (noisy) density; only a density within 1e-8 of zero
+    could sit in between.  And image_err_with_knife_edges measures an error on the knife-edge rays instead of skipping them."""
+    from oracle import checks as K
+    g = golden(name)
+    m = g.meta
+    if m["clamp"] != "relu" or not m["hierarchical"]:
+        pytest.skip("softplus is continuous")
+    out = run_oracle(g)
+    eps = T(g.get("eps_final"))
+    (p0, d0), (p1, d1) = K.knife_edge_branches(out.aux, m["R"], m["fov"], m["noise"], m["white_back"], m["last_back"], eps)
+    sig = torch.cat([out.aux["fine_rgb_sigma"][..., 3], out.aux["coarse_rgb_sigma"][..., 3]], -1)
+    last = torch.gather(sig, -1, out.aux["sort_idx"][..., -1:])[..., 0]
+    if eps is not None:
+        last = last + eps[..., -1] * m["noise"]
+    B, R = m["B"], m["R"]
+    pos = (last > 1e-8).reshape(B, R, R)
+    neg = (last <= 0).reshape(B, R, R)
+    assert (pos | neg).float().mean() > 0.999
+    assert torch.equal(torch.where(pos, d1, d0)[pos | neg], out.depth[pos | neg])
+    sel = (pos | neg).unsqueeze(1).expand_as(out.pixels)
+    assert torch.equal(torch.where(pos.unsqueeze(1), p1, p0)[sel], out.pixels[sel])
+    # a ray moved across the edge: the reference's OTHER branch is accepted, anything else is an error that is measured
+    edge = torch.zeros(B, R * R, dtype=torch.bool)
+    edge[0, 3] = True
+    other_p, other_d = torch.where(pos.unsqueeze(1), p0, p1), torch.where(pos, d0, d1)
+    px, dp = out.pixels.clone(), out.depth.clone()
+    px[0, :, 0, 3], dp[0, 0, 3] = other_p[0, :, 0, 3], other_d[0, 0, 3]
+    e_p, e_d, n = K.image_err_with_knife_edges(px, dp, out.pixels, out.depth, edge, ((p0, d0), (p1, d1)))
+    assert n == 1 and e_p == 0.0 and e_d == 0.0
+    px[0, :, 0, 3] += 0.5
+    e_p, _, _ = K.image_err_with_knife_edges(px, dp, out.pixels, out.depth, edge, ((p0, d0), (p1, d1)))
+    assert e_p > 0.1
+
+
+def test_accuracy_vs_fp64_of_the_reference_itself(golden):
+    """oracle/checks.py::field_fp64 / accuracy_vs_fp64: the fp32 reference against the same field in float64 at identical sample
+    positions.  Fed with the reference as "the implementation" the ratio is 1 by construction; the reference's own distance from
+    exact on this 4-layer FiLM network is 1.2e-4 of the rgb / sigma scale (maximum over 25 k values; more than the 1e-4 parity gate) -- the yardstick the GPU tests hold the HIP kernels to
+    (hip_vs_fp64 <= 2 x ref_vs_fp64)."""
+    from oracle import checks as K
+    g = golden("short_fg_small")
+    m = g.meta
+    pts = T(g["coarse_points"]).reshape(m["B"], -1, 3)
+    ex = K.field_fp64(m["variant"], {k: T(v) for k, v in g.params().items()}, T(g["feature_volume"]), T(g["global_feature"]), pts)
+    assert ex.dtype == torch.float64 and torch.get_default_dtype() == torch.float32
+    acc = K.accuracy_vs_fp64(g["coarse_rgb_sigma"], g["coarse_rgb_sigma"], ex)
+    print("reference fp32 vs fp64 on short_fg_small:", acc)
+    assert acc["ratio"] == 1.0 and 1e-6 < acc["ref_vs_fp64"] < 1e-3

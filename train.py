@@ -55,15 +55,16 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
+        import datetime
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        # generous watchdog: no rank waits for another's start-up work inside a collective any more (NodeLatch below), this is
+        # the second line of defence for a slow first step
+        dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(hours=1))
     import __graft_entry__ as ge
-    if rank == 0:
-        ge.build()
-    if world > 1:
-        dist.barrier()
-    import cnerf_amd
+    import cnerf_amd                                   # (the package loads libcnerf_hip.so lazily: importable before the build)
+    from cnerf_amd.training.latch import rank0_first
+    rank0_first(rank, "build", ge.build)               # rank 0 compiles, the others poll a marker file (no pending collective)
     from cnerf_amd.training import GanTrainer, default_metadata
     from cnerf_amd.training.gan_step import synthetic_sample
 
@@ -122,15 +123,19 @@ def main():
         # database instead of searching for ~7 minutes each, all at once)
         os.environ.setdefault("MIOPEN_USER_DB_PATH", os.path.join(os.path.expanduser("~"), ".config", "miopen"))
         warm = synthetic_sample(args.batch, args.img_size, args.voxel_res, dev, torch.Generator().manual_seed(1))
-        if rank == 0:
+        def search():
             t0 = time.perf_counter()
             trainer.warm_convolutions(warm)
             torch.cuda.synchronize()
             print(f"convolution kernels selected in {time.perf_counter() - t0:.1f} s (MIOpen find mode, results in {os.environ['MIOPEN_USER_DB_PATH']})", flush=True)
+
+        # rank 0 searches (minutes); the others poll a marker file meanwhile -- NOT a barrier: a rank waiting in an RCCL collective
+        # for longer than the process group's timeout aborts the job -- then read rank 0's results from the database
+        rank0_first(rank, "miopen_find", search)
         if world > 1:
-            dist.barrier()
             if rank != 0:
                 trainer.warm_convolutions(warm)
+                torch.cuda.synchronize()
             dist.barrier()
     for step in range(args.steps):
         sample = synthetic_sample(args.batch, args.img_size, args.voxel_res, dev, gen)
