@@ -189,7 +189,7 @@ def sample_composite_pass(args, gen, fvol, glob, cam, meta, evs):
     with torch.no_grad():
         gen(zin(gen, fvol, glob), cam, R, FOV, RAY_START, RAY_END, S, _aux=aux, **meta)
         fcl = ops.channel_last(fvol)
-        pts = torch.cat([aux["coarse_points"].reshape(B, -1, 3), aux["fine_points"].reshape(B, -1, 3)], 1).contiguous()
+        pts = [aux["coarse_points"].reshape(B, -1, 3).contiguous(), aux["fine_points"].reshape(B, -1, 3).contiguous()]
         allz = torch.cat([aux["fine_z"], aux["coarse_z"]], -1)
         allrs = torch.cat([aux["fine_rgb_sigma"], aux["coarse_rgb_sigma"]], -2)
         idx = aux["sort_idx"].long()
@@ -201,7 +201,8 @@ def sample_composite_pass(args, gen, fvol, glob, cam, meta, evs):
         for i in range(reps + 2):
             if i == 2:
                 evs.record(ev[0])
-            ops.gather_features(gen.siren, fcl, pts)
+            for p in pts:               # the lookups of the coarse and of the fine pass, as the fused kernels make them
+                ops.gather_features(gen.siren, fcl, p, R, S)
         evs.record(ev[1])
         for i in range(reps + 2):
             if i == 2:
@@ -211,7 +212,7 @@ def sample_composite_pass(args, gen, fvol, glob, cam, meta, evs):
         torch.cuda.synchronize()
     t_g = evs.elapsed_ms(ev[0], ev[1]) / reps
     t_c = evs.elapsed_ms(ev[2], ev[3]) / reps
-    evals, rays = pts.shape[0] * pts.shape[1], B * R * R
+    evals, rays = sum(p.shape[0] * p.shape[1] for p in pts), B * R * R
     bytes_g, bytes_c = evals * 1152.0, evals * 20.0 + rays * 16.0
     l2_gbps = (bytes_g + bytes_c) / ((t_g + t_c) * 1e-3) / 1e9
     out = {"kernels": "gather_kernel (cnerf_gather_features) + composite_kernel (cnerf_composite), unfused",

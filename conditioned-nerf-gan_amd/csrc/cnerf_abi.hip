@@ -387,6 +387,9 @@ int cnerf_gather_features(const cnerf_cfg* cfg, const float* fvol_cl, const floa
     if (!fvol_cl || !points || !feat || n_per_image < 1) return fail(CNERF_EINVAL, "gather_features: bad argument");
     if (cfg->C != 32 || cfg->n_levels > 1) return fail(CNERF_EINVAL, "gather_features: single 32-channel volume only");
     GatherArgs a{fvol_cl, points, feat, (long long)n_per_image, cfg->B, cfg->V, cfg->C, cfg->voxel_length / 2.0f};
+    // cfg->R, cfg->S describe the points' order when they are the samples of a render (n_per_image = R * R * S, ray-major): a
+    // visiting-order hint for the kernel's cache reuse, never a change of results
+    if ((long long)cfg->R * cfg->R * cfg->S == n_per_image) a.R = cfg->R, a.S = cfg->S;
     if (hipError_t e = launch_gather(a, (hipStream_t)stream)) return hip_fail(e, "gather");
     return CNERF_OK;
 }

@@ -170,6 +170,7 @@ struct GatherArgs {
     long long n_per_image;
     int B, V, C;
     float half_voxel;
+    int R = 0, S = 0;     // > 0: the points are the samples of R x R rays x S depths per image, ray-major (a visiting-order hint only)
 };
 hipError_t launch_gather(const GatherArgs& a, hipStream_t stream);
 hipError_t launch_scatter(const GatherArgs& a, const float* grad_feat, float* grad_fvol, hipStream_t stream);

@@ -5,6 +5,7 @@
 // Replaces fancy_integration (volumetric_rendering.py:18-70), sample_pdf (:297-342) with its call site
 // (generators.py:123-137), the cat/sort/gather merge (generators.py:162-167), the epilogue (generators.py:182-186,
 // distance2depth volumetric_rendering.py:345-356) and F.grid_sample + permute (siren.py:555-571).
+#include <cstdlib>
 #include "cnerf_dev.hpp"
 #include "cnerf_kernels.hpp"
 
@@ -532,26 +533,55 @@ __device__ __forceinline__ PointRange point_range(long long total) {
     return r;
 }
 
+__device__ __forceinline__ void gather_point(const GatherArgs& a, long long pt, int sub) {
+    const long long b = pt / a.n_per_image;
+    const float* p = a.points + pt * 3;
+    Corner8 cr;
+    trilinear_corners(__builtin_nontemporal_load(p), __builtin_nontemporal_load(p + 1), __builtin_nontemporal_load(p + 2), a.half_voxel, a.V, cr);
+    const float* vol = a.fvol + (size_t)b * a.V * a.V * a.V * 32 + 4 * sub;
+    f32x4 q[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) q[k] = *reinterpret_cast<const f32x4*>(vol + (size_t)cr.base[k] * 32);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = acc[e] + q[k][e] * cr.w[k];
+    // streamed once: the 128 B per point written here (and the positions read above) must not evict the volume's corner
+    // lines from the XCD's L2, which every neighbouring ray re-reads
+    __builtin_nontemporal_store(acc, reinterpret_cast<f32x4*>(a.feat + pt * 32 + 4 * sub));
+}
+
 __global__ __launch_bounds__(256) void gather_kernel(GatherArgs a) {
     const int sub = threadIdx.x & 7;
     const PointRange pr = point_range((long long)a.B * a.n_per_image);
-    for (long long pt = pr.begin; pt < pr.end; pt += pr.stride) {
-        const long long b = pt / a.n_per_image;
-        const float* p = a.points + pt * 3;
-        Corner8 cr;
-        trilinear_corners(__builtin_nontemporal_load(p), __builtin_nontemporal_load(p + 1), __builtin_nontemporal_load(p + 2), a.half_voxel, a.V, cr);
-        const float* vol = a.fvol + (size_t)b * a.V * a.V * a.V * 32 + 4 * sub;
-        f32x4 q[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) q[k] = *reinterpret_cast<const f32x4*>(vol + (size_t)cr.base[k] * 32);
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int k = 0; k < 8; ++k)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[e] = acc[e] + q[k][e] * cr.w[k];
-        // streamed once: the 128 B per point written here (and the positions read above) must not evict the volume's corner
-        // lines from the XCD's L2, which every neighbouring ray re-reads
-        __builtin_nontemporal_store(acc, reinterpret_cast<f32x4*>(a.feat + pt * 32 + 4 * sub));
+    for (long long pt = pr.begin; pt < pr.end; pt += pr.stride) gather_point(a, pt, sub);
+}
+
+// The same lookup with the points of a render visited patch by patch: when the caller says the points are the samples of R x R
+// rays x S depths in ray-major order (GatherArgs::R, S), the 32 points a block handles per iteration are PX x PY neighbouring
+// pixels x PD consecutive depths instead of 32 consecutive samples of ONE ray.  Consecutive samples of a ray are ~1.4 voxels
+// apart and share next to no corner lines; neighbouring pixels are ~0.4 voxel apart at the same depth, so the 256 corner lines a
+// tile asks for are a few dozen distinct ones and the repeats are served by the CU's vector L1 instead of by L2 (the kernel's
+// limiter at 1 KiB per point).  Which point a thread handles never changes what is computed for it: results are bit-identical.
+// Tile order = (image, patch row, patch column, depth slot) with the depth slot innermost, tiles dealt to the blocks of an XCD
+// class in a stride, so the tiles in flight on an XCD at any time are a compact slab of the volume (L2 locality as before).
+template <int PX, int PY, int PD>
+__global__ __launch_bounds__(256) void gather_patch_kernel(GatherArgs a) {
+    static_assert(PX * PY * PD == 32, "a block iteration covers 32 points");
+    const int sub = threadIdx.x & 7, q = threadIdx.x >> 3;
+    const int dx = q % PX, dy = (q / PX) % PY, dd = q / (PX * PY);
+    const int n_ds = a.S / PD, n_pc = a.R / PX, n_pr = a.R / PY;
+    const long long tpi = (long long)n_ds * n_pc * n_pr, total = tpi * a.B;
+    const int cls = blockIdx.x & 7, idx_in_cls = blockIdx.x >> 3;
+    const int blk_per_cls = (gridDim.x + 7 - cls) / 8;
+    const long long end = total * (cls + 1) / 8;
+    for (long long t = total * cls / 8 + idx_in_cls; t < end; t += blk_per_cls) {
+        const long long b = t / tpi;
+        const int r = (int)(t - b * tpi);
+        const int ds = r % n_ds, pc = (r / n_ds) % n_pc, prow = r / (n_ds * n_pc);
+        const int pixel = (prow * PY + dy) * a.R + pc * PX + dx;
+        gather_point(a, b * a.n_per_image + (long long)pixel * a.S + ds * PD + dd, sub);
     }
 }
 
@@ -619,7 +649,26 @@ hipError_t launch_transpose_cl(int B, int C, int V, const float* src, float* dst
     hipLaunchKernelGGL(transpose_cl_kernel, grid, dim3(256), 0, stream, src, dst, V3, C, to_channel_last ? 1 : 0);
     return hipGetLastError();
 }
+template <int PX, int PY, int PD>
+static bool try_gather_patch(const GatherArgs& a, hipStream_t stream) {
+    if (a.R <= 0 || a.S <= 0 || a.R % PX || a.R % PY || a.S % PD || (long long)a.R * a.R * a.S != a.n_per_image) return false;
+    long long blocks = (long long)a.B * (a.R / PX) * (a.R / PY) * (a.S / PD);
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    blocks = (blocks + 7) / 8 * 8;
+    hipLaunchKernelGGL((gather_patch_kernel<PX, PY, PD>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    return true;
+}
+
 hipError_t launch_gather(const GatherArgs& a, hipStream_t stream) {
+    // EXPERIMENT SWITCH (to be removed once measured): CNERF_GATHER_TILING = 0 linear, 1: 4x4x2, 2: 8x4x1, 3: 2x2x8, 4: 4x2x4, 5: 8x2x2
+    static const int mode = [] { const char* e = getenv("CNERF_GATHER_TILING"); return e ? atoi(e) : 1; }();
+    bool done = false;
+    if (mode == 1) done = try_gather_patch<4, 4, 2>(a, stream);
+    else if (mode == 2) done = try_gather_patch<8, 4, 1>(a, stream);
+    else if (mode == 3) done = try_gather_patch<2, 2, 8>(a, stream);
+    else if (mode == 4) done = try_gather_patch<4, 2, 4>(a, stream);
+    else if (mode == 5) done = try_gather_patch<8, 2, 2>(a, stream);
+    if (done) return hipGetLastError();
     const long long total = (long long)a.B * a.n_per_image;
     long long blocks = (total + 31) / 32;
     if (blocks > 256 * 16) blocks = 256 * 16;
