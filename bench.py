@@ -580,14 +580,26 @@ def stub_main(args, rank, world):
     args.img_size_full, args.img_size, args.num_steps, args.hidden = args.img_size, 16, 4, 64
     ddp, _ = train_step_ddp(args, torch.device("cpu"), rank, world, dist, stub=True)
     if rank == 0:
-        print(json.dumps({"metric": "rays/sec at 128x128x64spp ShapeNetCar", "unit": "rays/s", "n_gpus": world, "steps": args.steps,
+        emit_result({"metric": "rays/sec at 128x128x64spp ShapeNetCar", "unit": "rays/s", "n_gpus": world, "steps": args.steps,
                           "warmup": args.warmup, "value": whole_job_rays_per_s(world, args.batch, args.img_size_full, args.steps, elapsed),
                           "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                           "dtype": "none", "data": "stub: stand-in step on the CPU (launcher test), NOT a measurement",
-                          "config": {"workload": "stub"}, "train_step_ddp": ddp}), flush=True)
+                          "config": {"workload": "stub"}, "train_step_ddp": ddp})
     dist.barrier()
     dist.destroy_process_group()
     return 0
+
+
+_RESULT_FD = None
+
+
+def emit_result(res):
+    line = (json.dumps(res) + "\n").encode()
+    if _RESULT_FD is None:
+        sys.stdout.write(line.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_RESULT_FD, line)
 
 
 def main():
@@ -620,6 +632,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     args.gpus = world
+    # ONE line on stdout: libraries print there too (RCCL's version banner at communicator creation, MIOpen notices), so file
+    # descriptor 1 is pointed at stderr for the run and the JSON line goes to the saved original descriptor
+    sys.stdout.flush()
+    global _RESULT_FD
+    _RESULT_FD = os.dup(1)
+    os.dup2(2, 1)
     if args.device == "cpu":
         return stub_main(args, rank, world)
     torch.cuda.set_device(local_rank)
@@ -754,7 +772,7 @@ def main():
             res["cpu_baseline"] = base
             if not res["check"]["pass"]:
                 rc = 1
-        print(json.dumps(res), flush=True)
+        emit_result(res)
         if rc:
             sys.stderr.write("bench.py: the timed image FAILED the oracle check: " + json.dumps(res["check"]) + "\n")
     dist.barrier()

@@ -8,8 +8,8 @@ LIB_PATH = os.path.join(HERE, "libcnerf_hip.so")
 
 MAX_LAYERS = 16
 MAX_LEVELS = 4
-ABI_VERSION = 5
-F_HIERARCHICAL, F_WHITE_BACK, F_LAST_BACK, F_SOFTPLUS, F_SIGMOID_RGB, F_INPUT_XYZ, F_PAIRED_WAVES = 1, 2, 4, 8, 16, 32, 64
+ABI_VERSION = 6
+F_HIERARCHICAL, F_WHITE_BACK, F_LAST_BACK, F_SOFTPLUS, F_SIGMOID_RGB, F_INPUT_XYZ = 1, 2, 4, 8, 16, 32
 PREC_FP32, PREC_FP16, PREC_FP16X3 = 0, 1, 2
 PREC_CODE = {"fp32": PREC_FP32, "fp16": PREC_FP16, "fp16x3": PREC_FP16X3}
 LAYER_FILM, LAYER_SINE, LAYER_RES, LAYER_PFILM = 0, 1, 2, 3

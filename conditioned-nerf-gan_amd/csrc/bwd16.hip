@@ -591,13 +591,11 @@ __global__ __launch_bounds__(256) void chain16_kernel(Chain16Args A) {
                     const float gval = sg[p * 33 + ch];
                     const f32x4 w0 = *reinterpret_cast<const f32x4*>(sw + p * 8), w1 = *reinterpret_cast<const f32x4*>(sw + p * 8 + 4);
                     const u32x4 b0 = *reinterpret_cast<const u32x4*>(sb + p * 8), b1 = *reinterpret_cast<const u32x4*>(sb + p * 8 + 4);
-#ifndef C16_NOSCATTER
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         atomicAdd(gv + (size_t)b0[k] * C + ch, gval * w0[k]);
                         atomicAdd(gv + (size_t)b1[k] * C + ch, gval * w1[k]);
                     }
-#endif
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();

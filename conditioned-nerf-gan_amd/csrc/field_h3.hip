@@ -158,7 +158,7 @@ static hipError_t pack_impl(const float* w, int n_out, int K_real, int OT, bool 
 // bias / freq / phase of channels (r, r+1) of output tile t, lane half h, from LDS.  Issued one step ahead of their use:
 // an LDS read that is consumed at once stalls the wave for the full ds latency (lgkmcnt retires in order, behind the
 // A-fragment prefetches).
-// Folded FiLM (CNERF_H3_FOLD, default on).  arg = freq (acc / S + b) + phase is affine in the accumulator, and v_sin_f32 takes
+// Folded FiLM.  arg = freq (acc / S + b) + phase is affine in the accumulator, and v_sin_f32 takes
 // revolutions, so per image, matrix and channel three constants are prepared in LDS (in double, once per image and block):
 //     M = freq / (2 pi S) = Mh + Ml (two floats),   K = (freq b + phase) / (2 pi)
 // and the epilogue is  n = rint(acc Mh);  u = fma(acc, Ml, fma(acc, Mh, -n)) + K;  sin(2 pi u)  -- 5 vector ops + v_sin where the
@@ -167,14 +167,8 @@ static hipError_t pack_impl(const float* w, int n_out, int K_real, int OT, bool 
 // full magnitude (|arg| ~ 200 rad, ulp 1.5e-5 rad), so the result is within ~2e-7 rev of the exact affine map, where the
 // reference's own fp32 sequence (x = acc + b, freq x, + phase: three roundings at full magnitude) is ~1e-5 rad from it.
 // A plain sine layer is freq = 1, phase = 0.  The second matrix of a residual block (x + W2 y + b2) keeps the unfolded form.
-#ifndef CNERF_H3_FOLD
-#define CNERF_H3_FOLD 1
-#endif
-// CNERF_H3_FOLD_ML = 0 drops Ml (M rounded to fp32: one vector op and one LDS read per activation pair less; the error is the
-// size of one of the reference's own roundings of the argument: see CNERF_F32_FOLD_ML in field_kernel.hip)
-#ifndef CNERF_H3_FOLD_ML
-#define CNERF_H3_FOLD_ML 0
-#endif
+// Ml is dropped (M rounded to fp32: one vector op and one LDS read per activation pair less; the error is the size of one of the
+// reference's own roundings of the argument, measured in round 2: DESIGN.md 3.1)
 
 struct FilmPair {
     f32x2 fr, ph, bs;       // FOLD (non-residual matrices): fr = Mh, ph = Ml, bs = K
@@ -222,15 +216,15 @@ template <int STORE, bool RESID, int PHASE = 0>
 __device__ __forceinline__ void film_split_pair(const f32x16& acc, float inv_s, const FilmPair& f, int t, int h, int r, Split2* out2,
                                                 ActStore& st) {
     float a0 = 0.0f, a1 = 0.0f;
-    constexpr bool FOLD = CNERF_H3_FOLD && !RESID;
+    constexpr bool FOLD = !RESID;
     if (FOLD) {             // a0, a1 = the argument in revolutions, reduced to about [-1/2, 1/2] + K
         if (PHASE != 2) {
             const float n0 = __builtin_rintf(acc[r] * f.fr[0]);
-            a0 = (CNERF_H3_FOLD_ML ? __builtin_fmaf(acc[r], f.ph[0], __builtin_fmaf(acc[r], f.fr[0], -n0)) : __builtin_fmaf(acc[r], f.fr[0], -n0)) + f.bs[0];
+            a0 = __builtin_fmaf(acc[r], f.fr[0], -n0) + f.bs[0];
         }
         if (PHASE != 1) {
             const float n1 = __builtin_rintf(acc[r + 1] * f.fr[1]);
-            a1 = (CNERF_H3_FOLD_ML ? __builtin_fmaf(acc[r + 1], f.ph[1], __builtin_fmaf(acc[r + 1], f.fr[1], -n1)) : __builtin_fmaf(acc[r + 1], f.fr[1], -n1)) + f.bs[1];
+            a1 = __builtin_fmaf(acc[r + 1], f.fr[1], -n1) + f.bs[1];
         }
     } else {
     if (PHASE != 2) a0 = __builtin_fmaf(acc[r], inv_s, f.bs[0]);
@@ -314,24 +308,11 @@ __device__ __forceinline__ void film_split(const f32x16& acc, float inv_s, const
 // ---------------------------------------------------------------------------------------------------------------
 // weight units
 // ---------------------------------------------------------------------------------------------------------------
-// Weight units in flight: SLOTS LDS buffers, one barrier per SLOTS / 2 units (2: a barrier per unit).  Measured: halving
-// the barriers (-DCNERF_H3_SLOTS=4, 128 KiB of LDS) changes nothing (11.24 vs 11.21 ms per launch): the four waves arrive
-// together, the barrier is not where the time goes.  Default: two slots.
-#ifndef CNERF_H3_SLOTS
-#define CNERF_H3_SLOTS 2
-#endif
-// Epilogue placement inside the MFMA loop of a hidden layer: BALANCE splits every element pair over two k-chunks (about 13
-// vector slots in every chunk instead of ~26 in every second one); VPM = vector instructions the scheduler may place behind
-// each MFMA.  Measured (scripts/ab_h3.sh, field kernel per launch at the bench shape): unbalanced / VPM 7: 11.21 ms; balanced with
-// VPM 4 / 5 / 6 / 7: 11.36 / 11.38 / 11.47 / 11.52 ms (single-pass kernel 7.02 -> 7.47) -- the distribution of the vector work
-// over the gaps is not what limits this kernel (total vector issue + MFMA issue of the one wave per SIMD is: PMC table in
-// profiles/r02_kernel_counters.md).  Default: unbalanced.
-#ifndef CNERF_H3_BALANCE
-#define CNERF_H3_BALANCE 0
-#endif
-#ifndef CNERF_H3_VPM
-#define CNERF_H3_VPM 7
-#endif
+// Two weight units in LDS, one barrier per unit (four slots and a barrier per two units measured no different in round 2: the four
+// waves arrive together).  Epilogue placement inside the MFMA loop of a hidden layer: one element pair every second k-chunk, up to
+// H3_VPM vector instructions behind each MFMA (splitting every pair over two chunks measured 1-3 % slower: the distribution of the
+// vector work over the gaps is not what limits this kernel, total issue of the one wave per SIMD is -- profiles/r02_kernel_counters.md).
+constexpr int H3_VPM = 7;
 
 template <int NT>
 struct H3Lds {
@@ -469,16 +450,11 @@ __device__ __forceinline__ TilePoint tile_of_group(const FieldArgs& a, long long
     return p;
 }
 
-// PAIRED: four LDS slots, one barrier per TWO weight units (single-input networks: the unit's parity inside the tile is then
-// static in the unrolled loops); otherwise two slots and a barrier per unit.
-// Waves per SIMD the kernel is compiled for (register cap 512 / OCC): 1 = one block of four waves per CU.  The single-pass fp16
-// build holds half the operand registers, which is what a second resident block needs (build.py passes -DCNERF_H3_OCC for it).
-#ifndef CNERF_H3_OCC
-#define CNERF_H3_OCC 1
-#endif
-
-template <int NT, int STORE, bool PAIRED, bool HAS_RES>
-__global__ __launch_bounds__(256, CNERF_H3_OCC) void field_h3_kernel(FieldArgs a) {
+// One block of four waves per CU (512 registers per wave), two weight units in LDS, one barrier per unit.  (Measured in round 2
+// and not kept: four slots with a barrier per two units -- no change; two waves per SIMD by a register cap -- spills, slower; a
+// two-waves-per-tile variant of this kernel -- 11.7 vs 10.9 ms)
+template <int NT, int STORE, bool HAS_RES>
+__global__ __launch_bounds__(256) void field_h3_kernel(FieldArgs a) {
 #ifdef CNERF_STAMPS
     unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long last_ = __builtin_readcyclecounter();
@@ -487,7 +463,7 @@ __global__ __launch_bounds__(256, CNERF_H3_OCC) void field_h3_kernel(FieldArgs a
     constexpr int UNIT_FR = H3Lds<NT>::FRAGS;
     constexpr int H = NT * 32;
     constexpr int KCH = 2 * NT;
-    constexpr int SLOTS = PAIRED ? 4 : 2, PERIOD = SLOTS / 2;
+    constexpr int SLOTS = 2;                                        // weight units in LDS: one being read, one being copied
     f16x8* lds = reinterpret_cast<f16x8*>(smem);                                    // SLOTS weight units
     float* lds_bias = reinterpret_cast<float*>(smem + SLOTS * (size_t)UNIT_FR * 16);   // biases, head bias, 1/S per matrix, ones, zeros
     const float* lds_ones = lds_bias + a.bias_floats;
@@ -517,9 +493,9 @@ __global__ __launch_bounds__(256, CNERF_H3_OCC) void field_h3_kernel(FieldArgs a
     if (g_begin >= g_end) return;                                    // block-uniform
 
     // The block consumes one flat sequence of weight units: n_units per point tile (layer-0 unit per input tile, NT per
-    // hidden layer, head), tile after tile.  Unit i lives in LDS slot i % SLOTS; every PERIOD units one barrier publishes
-    // the PERIOD units copied during the previous period and frees the slots of the period before for the next copies.
-    const int n_units = a.n_in + (a.n_mats - 1) * NT + 1;           // >= 2; even when PAIRED (n_in == 1)
+    // hidden layer, head), tile after tile.  Unit i lives in LDS slot i % 2; the barrier at the start of a unit publishes the copy of
+    // that unit (issued one unit earlier) and frees the other slot for the next copy.
+    const int n_units = a.n_in + (a.n_mats - 1) * NT + 1;           // >= 2
     int dma_k = 0, dma_slot = 0;                                     // next unit to copy (index in the tile sequence), its slot
     int use_slot = 0;                                                // slot of the next unit to consume
     auto dma_next = [&]() {       // (past the block's last tile this re-copies units nobody reads: harmless, drained at the end)
@@ -527,23 +503,19 @@ __global__ __launch_bounds__(256, CNERF_H3_OCC) void field_h3_kernel(FieldArgs a
         dma_k = dma_k + 1 == n_units ? 0 : dma_k + 1;
         dma_slot = (dma_slot + 1) & (SLOTS - 1);
     };
-    // every wave, at the start of every unit; `first_of_period` is a compile-time fact at every call site
-    auto unit_begin = [&](bool first_of_period) -> const f16x8* {
-        if (first_of_period) {
-            __syncthreads();
-#pragma unroll
-            for (int i = 0; i < PERIOD; ++i) dma_next();
-        }
+    // every wave, at the start of every unit
+    auto unit_begin = [&]() -> const f16x8* {
+        __syncthreads();
+        dma_next();
         const f16x8* unit = lds + use_slot * UNIT_FR;
         use_slot = (use_slot + 1) & (SLOTS - 1);
         return unit;
     };
 
-    // prologue: biases and scales into LDS, the first PERIOD weight units (the first barrier publishes both); position and
-    // lookups of the first tile
+    // prologue: biases and scales into LDS, the first weight unit (the first barrier publishes both); position and lookups of
+    // the first tile
     for (int i = threadIdx.x; i < a.bias_floats + 2 * H; i += 256) lds_bias[i] = a.bias[i];
-#pragma unroll
-    for (int i = 0; i < PERIOD; ++i) dma_next();
+    dma_next();
     TilePoint tp = tile_of_group(a, g_begin, G, wave, j);
     float px, py, pz;
     tile_point(a, tp.b, tp.nn, tp.valid, h, true, px, py, pz);
@@ -555,14 +527,13 @@ __global__ __launch_bounds__(256, CNERF_H3_OCC) void field_h3_kernel(FieldArgs a
         const long long nn = tp.nn;
         const bool valid = tp.valid;
         BSTAMP(0);
-        if (b != staged_b && (a.freq || (CNERF_H3_FOLD && staged_b < 0))) {     // block-uniform
+        if (b != staged_b && (a.freq || staged_b < 0)) {     // block-uniform
             __syncthreads();                                        // nobody still reads the previous image's vectors
             if (a.freq)
                 for (int i = threadIdx.x; i < a.film_stride; i += 256) {
                     lds_freq[i] = a.freq[(size_t)b * a.film_stride + i];
                     lds_phase[i] = a.phase[(size_t)b * a.film_stride + i];
                 }
-#if CNERF_H3_FOLD
             for (int i = threadIdx.x; i < a.n_mats * H; i += 256) {
                 const int mm = i / H, ch = i - mm * H;
                 int film = -1, mats = 0, films = 0;                 // FiLM index of matrix mm (-1: plain sine / residual half)
@@ -580,7 +551,6 @@ __global__ __launch_bounds__(256, CNERF_H3_OCC) void field_h3_kernel(FieldArgs a
                 lds_ml[i] = (float)(M - (double)mh);
                 lds_k[i] = (float)((fr * (double)lds_bias[i] + ph) * 0.15915494309189533577);
             }
-#endif
             staged_b = b;
             __syncthreads();                                        // (once per image: not every unit starts with a barrier)
         }
@@ -615,12 +585,8 @@ __global__ __launch_bounds__(256, CNERF_H3_OCC) void field_h3_kernel(FieldArgs a
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc0[t][r] = 0.0f;
             for (int tk = 0; tk < a.n_in; ++tk) {
-#ifdef CNERF_H3_NOPREFETCH
-                input_tile_issue(a, b, tk, px, py, pz, h, it);
-#else
                 if (tk > 0) input_tile_issue(a, b, tk, px, py, pz, h, it);   // tile 0 was issued during the previous head
-#endif
-                const f16x8* unit = unit_begin(true);               // PAIRED: n_in == 1, unit 0 of the tile
+                const f16x8* unit = unit_begin();
                 const f32x16 feat = input_tile_reduce(it, px, py, pz, h);
                 float fv[16];
 #pragma unroll
@@ -650,8 +616,7 @@ __global__ __launch_bounds__(256, CNERF_H3_OCC) void field_h3_kernel(FieldArgs a
             const float inv_s = lds_inv_s[0];
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                if (CNERF_H3_FOLD) film_split<STORE, false>(acc0[t], inv_s, lds_k, lds_mh, lds_ml, t, h, &x[2 * t], st);
-                else film_split<STORE, false>(acc0[t], inv_s, bias, film ? lfr : lds_ones, film ? lph : lds_zeros, t, h, &x[2 * t], st);
+                film_split<STORE, false>(acc0[t], inv_s, lds_k, lds_mh, lds_ml, t, h, &x[2 * t], st);
             }
             if (STORE == STORE_F32) {
                 st.row_h += act_layer;
@@ -676,42 +641,24 @@ __global__ __launch_bounds__(256, CNERF_H3_OCC) void field_h3_kernel(FieldArgs a
             constexpr bool RESID = decltype(resid_tag)::value;
             const float inv_s = lds_inv_s[m];
             // folded constants of matrix m stand in for (bias, freq, phase) where the epilogue is the affine-then-sine one
-            constexpr bool FOLDED = CNERF_H3_FOLD && !RESID;
+            constexpr bool FOLDED = !RESID;
             const float* bias_l = FOLDED ? lds_k + (size_t)m * H : bias;
             const float* fr_l = FOLDED ? lds_mh + (size_t)m * H : fr_arg;
             const float* ph_l = FOLDED ? lds_ml + (size_t)m * H : ph_arg;
             f32x16 acc_prev;
             FilmPair fp;
-            [[maybe_unused]] FilmPair fp_done;            // (CNERF_H3_BALANCE only)
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                const f16x8* unit = unit_begin(!PAIRED || (t & 1));   // PAIRED: unit 1 + (m-1) NT + t of the tile, even iff t is odd
+                const f16x8* unit = unit_begin();
                 f32x16 acc;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-                acc = h3_tile_from_lds<NT, CNERF_H3_VPM>(unit, in, acc, lane, [&](int c) {
-#if CNERF_H3_BALANCE
-                    // epilogue of tile t-1, half a pair per chunk: chunk 2p fetches pair p's FiLM values (and finishes pair p-1),
-                    // chunk 2p+1 does pair p's first element; the last pair is finished behind the loop
-                    if (t > 0 && c < 16) {
-                        if (!(c & 1)) {
-                            if (c >= 2) film_split_pair<STORE, RESID, 2>(acc_prev, inv_s, fp_done, t - 1, h, c - 2, &out[2 * (t - 1)], st);
-                            fp = film_pair_load(bias_l, fr_l, ph_l, t - 1, h, c);
-                        } else {
-                            film_split_pair<STORE, RESID, 1>(acc_prev, inv_s, fp, t - 1, h, c - 1, &out[2 * (t - 1)], st);
-                            fp_done = fp;
-                        }
-                    }
-#else
+                acc = h3_tile_from_lds<NT, H3_VPM>(unit, in, acc, lane, [&](int c) {
                     if (t > 0 && c < 16) {                     // epilogue of tile t-1, one pair of elements per two chunks
                         if (!(c & 1)) fp = film_pair_load(bias_l, fr_l, ph_l, t - 1, h, c);
                         else film_split_pair<STORE, RESID>(acc_prev, inv_s, fp, t - 1, h, c - 1, &out[2 * (t - 1)], st);
                     }
-#endif
                 });
-#if CNERF_H3_BALANCE
-                if (t > 0) film_split_pair<STORE, RESID, 2>(acc_prev, inv_s, fp_done, t - 1, h, (KCH < 16 ? KCH : 16) - 2, &out[2 * (t - 1)], st);
-#endif
                 if (t > 0 && KCH < 16) {                       // narrow networks: the rest of tile t-1's elements
 #pragma unroll
                     for (int r = KCH; r < 16; r += 2)
@@ -752,12 +699,10 @@ __global__ __launch_bounds__(256, CNERF_H3_OCC) void field_h3_kernel(FieldArgs a
         // ---- head (last unit of the sequence).  Behind its barrier: layer-0 unit 0 streams in for the next group, the
         // next tile's position is finished and its 32 lookups are issued -- they fly under the head's MFMAs.
         {
-            const f16x8* unit = unit_begin(!PAIRED);                  // PAIRED: unit 1 + (n_mats-1) NT of the tile, odd
+            const f16x8* unit = unit_begin();
             float nx, ny, nz;                                   // without a next group: this tile again (harmless, keeps `it` dead above)
             tile_point_finish(a, tn.b, tn.nn, raw_next, tn.valid, h, has_next, nx, ny, nz);
-#ifndef CNERF_H3_NOPREFETCH
             input_tile_issue_volume(a, tn.b, 0, nx, ny, nz, h, it);
-#endif
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
@@ -789,342 +734,6 @@ __global__ __launch_bounds__(256, CNERF_H3_OCC) void field_h3_kernel(FieldArgs a
 #endif
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// Paired variant: TWO waves per 32-point tile, eight waves (two per SIMD) per block, so that one wave's epilogue and LDS
-// latency run under its partner's MFMAs (the single-wave kernel above cannot: it needs all 512 registers).  The pair splits
-// the K dimension by k-chunk parity: wave `role` (0 / 1) holds the activation chunks c = 2 i + role only -- half the operand
-// registers, which is what makes the second wave fit -- and multiplies its half of every weight row tile.  Registers
-// 8 role .. 8 role + 7 of output tile t are k-chunk 2 t + role of the next layer, i.e. each wave finishes HALF of every tile:
-// it hands the other eight accumulator registers to its partner through 2 KiB of LDS, published by the weight unit's barrier
-// that both cross anyway, adds the eight it receives and runs their epilogue under the MFMAs of the next unit -- the same
-// work in both waves, every unit.  Same packed weights, same fragments, same folded FiLM constants as above; each wave reads
-// only its chunks of a unit, so the LDS feed per MFMA is unchanged (+ 8 KiB of exchange per 32 KiB unit).  Layer 0 (a
-// single 32-channel input tile: nothing to split) is computed by both waves, each keeping its half of the registers; the
-// head's two partial sums meet through LDS.  Weight units ride a three-slot ring with a counted vmcnt wait (a unit is only
-// ~0.4 us of MFMAs per wave here).  Plain forward and the TB16-storing forward of single-input FiLM / sine networks;
-// everything else runs the kernel above.
-// ---------------------------------------------------------------------------------------------------------------
-#ifndef CNERF_H3_PAIRED
-#define CNERF_H3_PAIRED 0      // default for calls that do not set CNERF_F_PAIRED_WAVES; the environment variable of the same name overrides
-#endif
-#ifndef CNERF_H3P_VPM
-#define CNERF_H3P_VPM 7
-#endif
-struct Role0 { static constexpr int value = 0; };
-struct Role1 { static constexpr int value = 1; };
-
-// acc += W_unit[:, chunks 2 i + ROLE] * x_local[i], i < KC; the functor runs once per chunk (pipelined epilogue)
-template <int KC, int ROLE, int VALU_PER_MFMA, typename PerChunk>
-__device__ __forceinline__ f32x16 h3p_tile_from_lds(const f16x8* lds_tile, const Split2* x, f32x16 acc, int lane, PerChunk per_chunk) {
-    constexpr int AHEAD = 2;
-    f16x8 ring[AHEAD][PARTS];
-#pragma unroll
-    for (int i = 0; i < AHEAD; ++i)
-#pragma unroll
-        for (int k = 0; k < PARTS; ++k)
-            if (i < KC) ring[i][k] = lds_tile[((2 * i + ROLE) * PARTS + k) * 64 + lane];
-#pragma unroll
-    for (int c = 0; c < KC; ++c) {
-        f16x8 aw[PARTS];
-#pragma unroll
-        for (int k = 0; k < PARTS; ++k) aw[k] = ring[c % AHEAD][k];
-        if (c + AHEAD < KC) {
-#pragma unroll
-            for (int k = 0; k < PARTS; ++k) ring[c % AHEAD][k] = lds_tile[((2 * (c + AHEAD) + ROLE) * PARTS + k) * 64 + lane];
-        }
-        H3_MFMA3(acc, aw, x[c]);
-        per_chunk(c);
-        if (VALU_PER_MFMA > 0) {
-#pragma unroll
-            for (int m = 0; m < (PARTS == 1 ? 1 : 3); ++m) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, PARTS == 1 ? 3 * VALU_PER_MFMA : VALU_PER_MFMA, 0);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    return acc;
-}
-
-template <int NT, int STORE>
-__global__ __launch_bounds__(512) void field_h3p_kernel(FieldArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int UNIT_FR = H3Lds<NT>::FRAGS;
-    constexpr int PIECES = H3Lds<NT>::PIECES;
-    constexpr int PWC = (PIECES + 7) / 8;                 // 1-KiB pieces of a unit each of the eight waves copies
-    constexpr int H = NT * 32;
-    constexpr int KL = NT;                                // k-chunks of 16 a wave holds: c = 2 i + role
-    f16x8* lds = reinterpret_cast<f16x8*>(smem);                                       // ring of three weight units
-    float* lds_bias = reinterpret_cast<float*>(smem + 3 * (size_t)UNIT_FR * 16);       // biases, head bias, 1/S per matrix, ones, zeros
-    float* lds_mh = lds_bias + a.bias_floats + 2 * H;                                  // folded FiLM constants of the block's image
-    float* lds_ml = lds_mh + (size_t)a.n_mats * H;
-    float* lds_k = lds_ml + (size_t)a.n_mats * H;
-    float* xbuf = lds_k + (size_t)a.n_mats * H;                                        // inboxes [4 pairs][2 slots][2 roles][2][64 lanes] float4
-    float* hbuf = xbuf + 4 * 2 * 1024;                                                 // [4 pairs][32 points] float4: head partials
-    const float* lds_inv_s = lds_bias + (size_t)a.n_mats * H + 4;
-    const int lane = threadIdx.x & 63;
-    const int wave_u = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int pair = wave_u & 3, role = wave_u >> 2;
-    const int j = lane & 31, h = lane >> 5;
-
-    const long long G = (a.tiles_per_image + 3) / 4;
-    const long long total_groups = (a.total_tiles / a.tiles_per_image) * G;
-    const int nblk = gridDim.x;
-    const int cls = blockIdx.x & 7, idx_in_cls = blockIdx.x >> 3;
-    const int blk_per_cls = (nblk + 7 - cls) / 8;
-    const long long g_begin = total_groups * cls / 8 + idx_in_cls, g_end = total_groups * (cls + 1) / 8;
-    if (g_begin >= g_end) return;                                    // block-uniform
-
-    const f16x8* w_units = reinterpret_cast<const f16x8*>(a.packed);
-    const int n_units = 1 + (a.n_mats - 1) * NT + 1;                 // layer 0, NT per hidden matrix, head
-    int dma_k = 0, dma_slot = 0, use_slot = 0;
-    auto dma_next = [&]() {
-        const f16x8* src = w_units + (size_t)dma_k * UNIT_FR + lane;
-        f16x8* dst = lds + dma_slot * UNIT_FR;
-#pragma unroll
-        for (int q = 0; q < PWC; ++q) {
-            const int piece = wave_u * PWC + q;                      // wave-uniform
-#ifdef CNERF_H3P_NODMA                                               // timing diagnostics only (scripts/ab_h3p.sh): results are wrong
-            if (false)
-#else
-            if (piece < PIECES)
-#endif
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 64),
-                                                 (__attribute__((address_space(3))) void*)(dst + piece * 64), 16, 0, 0);
-        }
-        dma_k = dma_k + 1 == n_units ? 0 : dma_k + 1;
-        dma_slot = dma_slot == 2 ? 0 : dma_slot + 1;
-    };
-    // Every wave, at the start of every unit.  Unit k lives in slot k % 3 and was requested two units ago; vmcnt retires in
-    // order, so once at most the PWC pieces of the NEXT unit's copy (or anything younger) are outstanding, this wave's share of
-    // unit k has landed -- the copy of unit k + 1 stays in flight across the barrier (__syncthreads() would drain it, vmcnt(0),
-    // every time).  The barrier then publishes the unit and the partner's accumulator halves (ds_write: lgkmcnt(0)) and frees
-    // the slot of unit k - 1 for the copy of unit k + 2.
-    auto unit_begin = [&]() -> const f16x8* {
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(PWC) : "memory");
-        dma_next();
-        const f16x8* unit = lds + use_slot * UNIT_FR;
-        use_slot = use_slot == 2 ? 0 : use_slot + 1;
-        return unit;
-    };
-    auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };     // publishes LDS writes only
-
-    for (int i = threadIdx.x; i < a.bias_floats + 2 * H; i += 512) lds_bias[i] = a.bias[i];
-    dma_next();
-    dma_next();
-    int staged_b = -1;
-
-    auto run = [&](auto role_tag) {
-        constexpr int ROLE = decltype(role_tag)::value;
-        // this wave's inbox (written by the partner) and outbox (the partner's inbox) for unit parity `slot`
-        auto inbox = [&](int slot) { return reinterpret_cast<f32x4*>(xbuf + ((pair * 2 + slot) * 2 + ROLE) * 512) + lane; };
-        auto outbox = [&](int slot) { return reinterpret_cast<f32x4*>(xbuf + ((pair * 2 + slot) * 2 + (1 - ROLE)) * 512) + lane; };
-        // registers 8 ROLE .. 8 ROLE + 7 of a tile's accumulator += the partner's partial sums for them
-        auto add_inbox = [&](f32x16& acc, int slot) {
-            const f32x4* src = inbox(slot);
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const f32x4 v = src[q * 64];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[8 * ROLE + 4 * q + e] += v[e];
-            }
-        };
-        auto send_outbox = [&](const f32x16& acc, int slot) {
-            f32x4* dst = outbox(slot);
-            constexpr int O = 8 * (1 - ROLE);
-#pragma unroll
-            for (int q = 0; q < 2; ++q) dst[q * 64] = f32x4{acc[O + 4 * q], acc[O + 4 * q + 1], acc[O + 4 * q + 2], acc[O + 4 * q + 3]};
-        };
-        for (long long g = g_begin; g < g_end; g += blk_per_cls) {
-            const TilePoint tp = tile_of_group(a, g, G, pair, j);
-            const int b = tp.b;
-            const long long nn = tp.nn;
-            const bool valid = tp.valid;
-            if (b != staged_b && (a.freq || staged_b < 0)) {            // block-uniform: folded FiLM constants of the image
-                __syncthreads();
-                for (int i = threadIdx.x; i < a.n_mats * H; i += 512) {
-                    const int mm = i / H, ch = i - mm * H;
-                    int film = -1, films = 0;
-                    for (int l = 0; l < a.L; ++l) {
-                        if (a.layer_kind[l] == CNERF_LAYER_FILM && l == mm) film = films;
-                        films += a.layer_kind[l] == CNERF_LAYER_FILM;
-                    }
-                    const double fr = film >= 0 ? (double)a.freq[(size_t)b * a.film_stride + (size_t)film * H + ch] : 1.0;
-                    const double ph = film >= 0 ? (double)a.phase[(size_t)b * a.film_stride + (size_t)film * H + ch] : 0.0;
-                    const double M = fr * (double)lds_inv_s[mm] * 0.15915494309189533577;
-                    const float mh = (float)M;
-                    lds_mh[i] = mh;
-                    lds_ml[i] = (float)(M - (double)mh);
-                    lds_k[i] = (float)((fr * (double)lds_bias[i] + ph) * 0.15915494309189533577);
-                }
-                staged_b = b;
-                __syncthreads();
-            }
-            float px, py, pz;
-            tile_point(a, b, nn, valid, h, ROLE == 0, px, py, pz);         // (one wave of the pair writes z / points)
-            InputTile it;
-            input_tile_issue_volume(a, b, 0, px, py, pz, h, it);
-
-            // activation chunks of this wave: local index i <-> k-chunk 2 i + ROLE (= registers 8 ROLE .. of output tile i).  One
-            // spare slot in front: the epilogue helpers address "chunk r >> 3 of the tile's pair", i.e. slot i - ROLE + (r >> 3).
-            Split2 xbuf_[KL + 1], ybuf_[KL + 1];
-            Split2 *x = xbuf_ + 1, *y = ybuf_ + 1;
-            ActStore st;
-            st.row_h = st.row_c = nullptr;
-            const long long tile_in_image = (g - (long long)b * G) * 4 + pair;
-            const long long tile_T = (long long)b * a.tiles_per_image + tile_in_image;
-            const size_t slab16 = (size_t)a.total_tiles * NT * 1024;
-            st.live = tile_in_image < a.tiles_per_image;
-            st.blk_h = STORE == STORE_TB16 ? reinterpret_cast<_Float16*>(a.act_h) + ((size_t)tile_T * NT * 32 + j) * 32 : nullptr;
-            st.blk_c = STORE == STORE_TB16 ? reinterpret_cast<_Float16*>(a.act_c) + ((size_t)tile_T * NT * 256 + lane) * 4 : nullptr;
-            // the four element pairs of this wave's half of tile t: registers r = 8 ROLE + 2 q
-            auto half_epilogue_pair = [&](const f32x16& acc, float inv_s, const FilmPair& fp, int t, int q, Split2* dst_chunks) {
-                const int r = 8 * ROLE + 2 * q;
-                Split2* out2 = dst_chunks + t - ROLE;                       // out2[r >> 3] == dst_chunks[t]
-                film_split_pair<STORE, false>(acc, inv_s, fp, t, h, r, out2, st);
-                // pin the pair's fragment dwords here: left alone, instruction selection sinks every epilogue of a layer to the
-                // point where the chunks are consumed, which keeps all accumulators alive and leaves nothing to run under MFMAs
-#pragma unroll
-                for (int pk = 0; pk < PARTS; ++pk) asm volatile("" : "+v"(dst_chunks[t].p[pk][q]));
-            };
-            // ---- layer 0: both waves compute every output tile (one input tile: no k to split), each keeps its half ----------------
-            {
-                const f16x8* unit = unit_begin();
-                const f32x16 feat = input_tile_reduce(it, px, py, pz, h);
-                float fv[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) fv[r] = feat[r];
-                if (STORE == STORE_TB16 && st.live && ROLE == 0) {
-                    _Float16* fo = reinterpret_cast<_Float16*>(a.act_feat) + (((size_t)tile_T * a.n_in) * 32 + j) * 32 + 4 * h;
-#pragma unroll
-                    for (int gq = 0; gq < 4; ++gq) {
-                        float c4[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) c4[e] = __builtin_amdgcn_fmed3f(fv[4 * gq + e], -65504.0f, 65504.0f);
-                        *reinterpret_cast<u32x2_*>(fo + 8 * gq) = u32x2_{pk_f16(c4[0], c4[1]), pk_f16(c4[2], c4[3])};
-                    }
-                }
-                Split2 f2[2];
-                f2[0] = split8_clamped(fv);
-                f2[1] = split8_clamped(fv + 8);
-                const float inv_s = lds_inv_s[0];
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    f32x16 acc;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-#pragma unroll
-                    for (int sch = 0; sch < 2; ++sch) {
-                        f16x8 aw[PARTS];
-#pragma unroll
-                        for (int k = 0; k < PARTS; ++k) aw[k] = unit[((2 * t + sch) * PARTS + k) * 64 + lane];
-                        H3_MFMA3(acc, aw, f2[sch]);
-                    }
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        half_epilogue_pair(acc, inv_s, film_pair_load(lds_k, lds_mh, lds_ml, t, h, 8 * ROLE + 2 * q), t, q, x);
-                }
-                if (STORE == STORE_TB16) {
-                    st.blk_h += slab16;
-                    st.blk_c += slab16;
-                }
-            }
-            // ---- hidden layers: one weight unit per output tile, k-chunks split by parity over the pair ---------------------------
-            for (int m = 1; m < a.n_mats; ++m) {
-                const float inv_s = lds_inv_s[m];
-                const float* kk = lds_k + (size_t)m * H;
-                const float* mh = lds_mh + (size_t)m * H;
-                const float* ml = lds_ml + (size_t)m * H;
-                f32x16 acc_prev;
-                FilmPair fp;
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const f16x8* unit = unit_begin();
-                    if (t > 0) add_inbox(acc_prev, (t - 1) & 1);
-                    f32x16 acc;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-                    // epilogue of this wave's half of tile t - 1 (4 element pairs) spread over the KL chunks: constants fetched
-                    // one step before their use (an LDS read consumed at once stalls for the whole ds latency)
-                    constexpr int STEP = KL / 4 > 0 ? KL / 4 : 1;           // chunks per pair
-                    constexpr int PPC = 4 / KL > 0 ? 4 / KL : 1;            // pairs per chunk (narrow networks)
-                    acc = h3p_tile_from_lds<KL, ROLE, CNERF_H3P_VPM>(unit, x, acc, lane, [&](int c) {
-#ifdef CNERF_H3P_NOEPI
-                        if (false) {
-#else
-                        if (t > 0) {
-#endif
-                            if (STEP > 1) {
-                                // Staggered: role 0 runs its four pairs in the first half of the unit, role 1 in the second, so
-                                // that a wave's vector work meets its SIMD partner's MFMAs instead of its vector work (the two
-                                // leave every barrier together and would otherwise run in lockstep: MI355X_MICROARCH.md item 9).
-                                constexpr int BASE = ROLE * (KL - 4);
-                                if (c == BASE - 1 || (BASE == 0 && c == 0)) fp = film_pair_load(kk, mh, ml, t - 1, h, 8 * ROLE);
-                                if (c >= BASE && c < BASE + 4) {
-                                    const int q = c - BASE;
-                                    half_epilogue_pair(acc_prev, inv_s, fp, t - 1, q, y);
-                                    if (q + 1 < 4) fp = film_pair_load(kk, mh, ml, t - 1, h, 8 * ROLE + 2 * (q + 1));
-                                }
-                            } else {
-#pragma unroll
-                                for (int qq = 0; qq < PPC; ++qq) {
-                                    const int q = c * PPC + qq;
-                                    if (q < 4) half_epilogue_pair(acc_prev, inv_s, film_pair_load(kk, mh, ml, t - 1, h, 8 * ROLE + 2 * q), t - 1, q, y);
-                                }
-                            }
-                        }
-                    });
-                    send_outbox(acc, t & 1);
-                    acc_prev = acc;
-                }
-                // the layer's last tile: its halves are published by one more barrier, the two half epilogues have no MFMAs to hide under
-                lds_barrier();
-                add_inbox(acc_prev, (NT - 1) & 1);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) half_epilogue_pair(acc_prev, inv_s, film_pair_load(kk, mh, ml, NT - 1, h, 8 * ROLE + 2 * q), NT - 1, q, y);
-#pragma unroll
-                for (int c = 0; c < KL; ++c) x[c] = y[c];
-                if (STORE == STORE_TB16) {
-                    st.blk_h += slab16;
-                    st.blk_c += slab16;
-                }
-            }
-            // ---- head: two partial sums over the k halves ------------------------------------------------------------------------------
-            {
-                const f16x8* unit = unit_begin();
-                f32x16 acc;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-                acc = h3p_tile_from_lds<KL, ROLE, 0>(unit, x, acc, lane, [](int) {});
-                if (ROLE == 1 && h == 0) *reinterpret_cast<f32x4*>(hbuf + (pair * 32 + j) * 4) = f32x4{acc[0], acc[1], acc[2], acc[3]};
-                lds_barrier();
-                if (ROLE == 0 && valid && h == 0) {
-                    const f32x4 other = *reinterpret_cast<const f32x4*>(hbuf + (pair * 32 + j) * 4);
-                    const f32x4 hb = *reinterpret_cast<const f32x4*>(lds_bias + (size_t)a.n_mats * H);
-                    const float inv_s = lds_inv_s[a.n_mats];
-                    f32x4 o;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) o[i] = __builtin_fmaf(acc[i] + other[i], inv_s, hb[i]);
-                    if (a.flags & CNERF_F_SIGMOID_RGB) {
-                        o[0] = sigmoidf_(o[0]);
-                        o[1] = sigmoidf_(o[1]);
-                        o[2] = sigmoidf_(o[2]);
-                    }
-                    *reinterpret_cast<f32x4*>(a.rgb_sigma + ((size_t)b * a.n_per_image + nn) * 4) = o;
-                }
-            }
-        }
-    };
-    if (role == 0) run(Role0{});
-    else run(Role1{});
-    __syncthreads();                                                 // drain the copies issued for tiles this block does not have
-}
-
-template <int NT>
-static size_t h3p_lds_bytes(const FieldArgs& a) {
-    return 3 * (size_t)H3Lds<NT>::FRAGS * 16 + ((size_t)a.bias_floats + 2 * NT * 32 + 3 * (size_t)a.n_mats * NT * 32 + 4 * 2 * 1024 + 4 * 32 * 4) * 4;
-}
-
 constexpr size_t LDS_LIMIT = 160 * 1024;
 
 template <int NT>
@@ -1135,56 +744,28 @@ static size_t h3_lds_bytes(const FieldArgs& a, int slots) {
            ((size_t)a.bias_floats + 2 * NT * 32 + 2 * (size_t)a.film_stride + 3 * (size_t)a.n_mats * NT * 32) * 4;
 }
 
-template <int NT, int STORE, bool PAIRED, bool HAS_RES>
+template <int NT, int STORE, bool HAS_RES>
 static hipError_t launch_h3_inst(const FieldArgs& a, hipStream_t stream) {
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) != hipSuccess) dev = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
-    const size_t lds_bytes = h3_lds_bytes<NT>(a, PAIRED ? 4 : 2);
+    const size_t lds_bytes = h3_lds_bytes<NT>(a, 2);
     if (lds_bytes > LDS_LIMIT) return hipErrorInvalidValue;
     // (per launch, not once per process: the attribute is per device, and a cached flag would be unsynchronised global state)
-    if (hipError_t e = hipFuncSetAttribute((const void*)field_h3_kernel<NT, STORE, PAIRED, HAS_RES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT)) return e;
+    if (hipError_t e = hipFuncSetAttribute((const void*)field_h3_kernel<NT, STORE, HAS_RES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT)) return e;
     const long long want = (a.total_tiles / a.tiles_per_image) * ((a.tiles_per_image + 3) / 4);
-    const long long cap = (long long)cus * (CNERF_H3_OCC * lds_bytes <= LDS_LIMIT ? CNERF_H3_OCC : 1);
-    int blocks = (int)(want < cap ? want : cap);
+    int blocks = (int)(want < cus ? want : cus);        // one block of four waves per CU (512 registers per wave)
     if (blocks < 8) blocks = 8;
     blocks = (blocks + 7) / 8 * 8;
-    hipLaunchKernelGGL((field_h3_kernel<NT, STORE, PAIRED, HAS_RES>), dim3(blocks), dim3(256), lds_bytes, stream, a);
+    hipLaunchKernelGGL((field_h3_kernel<NT, STORE, HAS_RES>), dim3(blocks), dim3(256), lds_bytes, stream, a);
     return hipGetLastError();
-}
-
-template <int NT, int STORE>
-static hipError_t launch_h3p(const FieldArgs& a, hipStream_t stream) {
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
-    const size_t lds_bytes = h3p_lds_bytes<NT>(a);
-    if (hipError_t e = hipFuncSetAttribute((const void*)field_h3p_kernel<NT, STORE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT)) return e;
-    const long long want = (a.total_tiles / a.tiles_per_image) * ((a.tiles_per_image + 3) / 4);
-    int blocks = (int)(want < cus ? want : cus);
-    if (blocks < 8) blocks = 8;
-    blocks = (blocks + 7) / 8 * 8;
-    hipLaunchKernelGGL((field_h3p_kernel<NT, STORE>), dim3(blocks), dim3(512), lds_bytes, stream, a);
-    return hipGetLastError();
-}
-
-static bool h3_paired_enabled() {
-    static const int on = [] { const char* e = getenv("CNERF_H3_PAIRED"); return e ? atoi(e) : CNERF_H3_PAIRED; }();
-    return on != 0;
 }
 
 template <int NT, int STORE>
 static hipError_t launch_h3_nt(const FieldArgs& a, hipStream_t stream) {
-    // one barrier per two weight units where the unit parity is static (single-input networks) and four slots fit in LDS
     bool res = false;
     for (int l = 0; l < a.L; ++l) res |= a.layer_kind[l] == CNERF_LAYER_RES;
-    if constexpr (STORE != STORE_F32) {
-        if ((h3_paired_enabled() || (a.flags & CNERF_F_PAIRED_WAVES)) && !res && a.n_in == 1 && a.n_mats == a.L && a.n_mats >= 2 && h3p_lds_bytes<NT>(a) <= LDS_LIMIT)
-            return launch_h3p<NT, STORE>(a, stream);
-    }
-    if (res) return launch_h3_inst<NT, STORE, false, true>(a, stream);
-    if (CNERF_H3_SLOTS == 4 && a.n_in == 1 && h3_lds_bytes<NT>(a, 4) <= LDS_LIMIT) return launch_h3_inst<NT, STORE, true, false>(a, stream);
-    return launch_h3_inst<NT, STORE, false, false>(a, stream);
+    return res ? launch_h3_inst<NT, STORE, true>(a, stream) : launch_h3_inst<NT, STORE, false>(a, stream);
 }
 
 static hipError_t field_impl(const FieldArgs& a, int H, hipStream_t stream) {

@@ -79,9 +79,6 @@ constexpr int RING = CNERF_RING;
 // Forward epilogue sine.  v_sin_f32 behind an exact reduction by 2 pi (max abs error 3.8e-7, scripts/ubench/vsin_accuracy.hip)
 // instead of the 12-op polynomial (1.2e-7) is +1.7 % throughput, but on this exact path it pushes one random-input parity
 // case (test_render_matches_oracle_random_inputs, sigma head x30) from 0.9e-4 to 1.03e-4 of the 1e-4 gate: off.
-#ifndef CNERF_F32_HW_SIN
-#define CNERF_F32_HW_SIN 0
-#endif
 
 // epilogue kinds
 enum { EPI_FILM = 0, EPI_FILM_RES = 1 };
@@ -93,47 +90,30 @@ enum { EPI_FILM = 0, EPI_FILM_RES = 1 };
 // 5 vector ops + v_sin instead of 2 + the 12-op reduce-and-polynomial sine.  pre * Mh - n is a single-rounding fma of
 // magnitude <= 1/2: the argument never exists rounded at its full magnitude (~200 rad, ulp 1.5e-5), which more than pays
 // for v_sin's 3.8e-7 against the polynomial's 1.2e-7 (the reason the hardware sine alone was rejected above).
-#ifndef CNERF_F32_FOLD
-#define CNERF_F32_FOLD 1
-#endif
 // CNERF_F32_FOLD_ML = 0 (default) drops the low part of M, one vector op per activation less: M is then freq / 2 pi rounded to
 // fp32, a relative 6e-8, i.e. up to ~2e-6 revolutions on an argument of ~30 -- the size of ONE of the three roundings the
 // reference's own fp32 sequence makes at that magnitude.  Measured: 28.9 -> 28.4 ms per launch, parity unchanged (timed image of
 // bench.py: rgb / sigma 6.9e-5 / 7.8e-5 coarse / fine with Ml, 7.1e-5 / 7.2e-5 without; every parity test passes either way).
-#ifndef CNERF_F32_FOLD_ML
-#define CNERF_F32_FOLD_ML 0
-#endif
 __device__ __forceinline__ float folded_sine(float pre, float mh, float ml, float k) {
     const float n = __builtin_rintf(pre * mh);
-#if CNERF_F32_FOLD_ML
-    return __builtin_amdgcn_sinf(__builtin_fmaf(pre, ml, __builtin_fmaf(pre, mh, -n)) + k);
-#else
     return __builtin_amdgcn_sinf(__builtin_fmaf(pre, mh, -n) + k);
-#endif
 }
 
 // WFOLD: the scale is folded into the WEIGHTS, per image (a residual matrix adds its block input, scaled by 1 / 2 pi, in the epilogue) -- W'_b = diag(freq_b / 2 pi) W, packed per call into the
 // workspace (scale_packed_kernel), the accumulator starts from K_b = (freq_b bias + phase_b) / 2 pi -- so the accumulator IS the
 // argument in revolutions and the activation is sin(2 pi fract(acc)): one vector op + v_sin, no per-channel constants in the
 // epilogue.  Numerically the sum is rounded at the same relative precision as before; the weights carry one more rounding (6e-8).
-#ifndef CNERF_F32_WFOLD
-#define CNERF_F32_WFOLD 1
-#endif
 // Reduction of the accumulator (revolutions) in front of v_sin_f32, which is specified for |u| <= 256 only -- the WFOLD template
 // argument of the kernels (0 = no weight folding):
 //   1: v_fract_f32 -- one vector op, any magnitude; [0, 1) instead of [-0.5, 0.5] costs half an ulp of 1 on a negative argument
 //      (<= 2.7e-7 abs instead of 1.2e-7).  Networks with FiLM layers (arguments of tens of radians: ulp 4e-6 and more).
 //   2: u - rint(u) -- two vector ops, exact, 1.2e-7.  Networks of plain sine layers / residual blocks, whose hidden arguments are
 //      a few radians: there the half ulp of `fract` is visible (sigma of tests/golden/short_f_small 1.6e-5 -> 6.3e-5 of its scale).
-// (v_sin_f32 alone also reduces by itself, 1.2e-7 for |u| <= 250, but returns 0 beyond 256 revolutions: measurement only,
-// -DCNERF_F32_WFOLD_REDUCE=0.)  scripts/ab_wfold_raw.sh, scripts/ubench/vsin_raw_range.hip, profiles/r02_vsin_reduction.txt
-#ifndef CNERF_F32_WFOLD_REDUCE
-#define CNERF_F32_WFOLD_REDUCE (-1)    // -1: as the kernel's WFOLD argument says; 0 / 1 / 2: none / fract / rint everywhere (experiments)
-#endif
+// (v_sin_f32 alone also reduces by itself, 1.2e-7 for |u| <= 250, but returns 0 beyond 256 revolutions: measured in round 2 and
+// not shipped.)  scripts/ubench/vsin_raw_range.hip, profiles/r02_vsin_reduction.txt
 template <int WFOLD>
 __device__ __forceinline__ float wfolded_sine(float u) {
-    constexpr int mode = CNERF_F32_WFOLD_REDUCE >= 0 ? CNERF_F32_WFOLD_REDUCE : WFOLD;
-    return __builtin_amdgcn_sinf(mode == 1 ? __builtin_amdgcn_fractf(u) : mode == 2 ? u - __builtin_rintf(u) : u);
+    return __builtin_amdgcn_sinf(WFOLD == 1 ? __builtin_amdgcn_fractf(u) : u - __builtin_rintf(u));
 }
 
 template <int EPI, bool STORE>
@@ -145,11 +125,7 @@ __device__ __forceinline__ float epilogue_one(float acc, float res, float fr, fl
         sincos_pi_reduced(fr * pre + ph, sn, cs);
         return sn;
     }
-#if CNERF_F32_HW_SIN
-    return sin_2pi_reduced_hw(fr * pre + ph);
-#else
     return sin_pi_reduced(fr * pre + ph);
-#endif
 }
 
 // row-major activation store of one output tile: lane (j,h) owns channels 32t + 8g + 4h + e of its point
@@ -286,15 +262,11 @@ __device__ __forceinline__ void film_all(const f32x16* y, f32x16* x, const float
     f32x16 fr_n = load_chan16(freq, 0, h), ph_n = load_chan16(phase, 0, h);      // per-channel vectors one tile ahead of their use
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-#if CNERF_F32_FILM_PREFETCH
         const f32x16 fr = fr_n, ph = ph_n;
         if (t + 1 < NT) {
             fr_n = load_chan16(freq, t + 1, h);
             ph_n = load_chan16(phase, t + 1, h);
         }
-#else
-        const f32x16 fr = t == 0 ? fr_n : load_chan16(freq, t, h), ph = t == 0 ? ph_n : load_chan16(phase, t, h);
-#endif
         f32x16 o, cs;
         if (WFOLD) {
 #pragma unroll
@@ -342,15 +314,6 @@ __device__ __forceinline__ void film_all(const f32x16* y, f32x16* x, const float
 // from layer 0 but the 32 scattered global_load_lds instructions cost 8.6 k cycles to issue in the head (~200 cycles each:
 // M0 rewrite + 32 distinct lines per instruction), a net loss of 0.5 %; only the one-tile-ahead fetch of the raw sample
 // coordinate is kept by default.
-#ifndef CNERF_F32_FILM_PREFETCH
-#define CNERF_F32_FILM_PREFETCH 1
-#endif
-#ifndef CNERF_F32_HEAD_LDS
-#define CNERF_F32_HEAD_LDS 1
-#endif
-#ifndef CNERF_F32_LOOKUP_DMA
-#define CNERF_F32_LOOKUP_DMA 0
-#endif
 
 template <int NT, bool HAS_RES, bool STORE, bool DROP, bool FOLD = false, int WFOLD = 0>
 __global__ __launch_bounds__(256) void field_tile_kernel(FieldArgs a) {
@@ -363,22 +326,14 @@ __global__ __launch_bounds__(256) void field_tile_kernel(FieldArgs a) {
     constexpr int H = NT * 32;
     constexpr size_t TILE4 = 4 * 64;   // float4 per (t, tk) pair
 
-    // Cross-tile prefetch (wide networks: one block per CU anyway): the lookups of a tile's first input tile are issued as
-    // LDS-DMA during the previous tile's head, the raw sample coordinate one tile earlier still.
-    constexpr bool PF = CNERF_F32_LOOKUP_DMA && NT >= 4;
-    extern __shared__ __attribute__((aligned(16))) char smem_q[];
-    f32x4* lds_wave = reinterpret_cast<f32x4*>(smem_q) + (threadIdx.x >> 6) * (32 * 64);     // 32 KiB per wave
-
     // The head's weights (4x4x1 MFMA layout: NT*4 float4 per lane) are read in full by every wave for every tile -- as many
     // bytes as the lookups.  They are parked in LDS once per block instead of streamed from L2 once per tile.
-#if CNERF_F32_HEAD_LDS
     __shared__ f32x4 s_head[NT * 4 * 64];
     {
         const f32x4* head_w = reinterpret_cast<const f32x4*>(a.packed) + ((size_t)NT * a.n_in + (size_t)(a.n_mats - 1) * NT * NT) * TILE4;
         for (int i = threadIdx.x; i < NT * 4 * 64; i += 256) s_head[i] = head_w[i];
         __syncthreads();
     }
-#endif
 
     const TileRange tr = tile_range(a.total_tiles);
     auto point_of = [&](long long tile, int& b_, long long& nn_, bool& valid_) {
@@ -394,7 +349,6 @@ __global__ __launch_bounds__(256) void field_tile_kernel(FieldArgs a) {
     if (tr.begin < tr.end) {
         point_of(tr.begin, b, nn, valid);
         tile_point(a, b, nn, valid, h, true, px, py, pz);
-        if (PF) input_tile_dma(a, b, 0, px, py, pz, h, lds_wave);
     }
     for (long long tile = tr.begin; tile < tr.end; tile += tr.stride) {
         STAMP(0);   // loop overhead / previous store
@@ -430,7 +384,7 @@ __global__ __launch_bounds__(256) void field_tile_kernel(FieldArgs a) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) y.v[t] = load_chan16(bias, t, h);
         for (int tk = 0; tk < a.n_in; ++tk) {
-            const f32x16 feat = (PF && tk == 0) ? input_tile_from_lds(a, 0, px, py, pz, h, lds_wave, lane) : input_tile(a, b, tk, px, py, pz, h);
+            const f32x16 feat = input_tile(a, b, tk, px, py, pz, h);
             if (STORE) {
                 float* fo = a.act_feat + gpt * (32 * a.n_in) + 32 * tk + 4 * h;
 #pragma unroll
@@ -517,18 +471,12 @@ __global__ __launch_bounds__(256) void field_tile_kernel(FieldArgs a) {
         // ---- next tile: finish its position, send its lookups off; they land under the head and the loop overhead ----------
         float nx, ny, nz;
         tile_point_finish(a, nb, nnn, raw_next, nvalid, h, has_next, nx, ny, nz);
-        if (PF) input_tile_dma(a, nb, 0, nx, ny, nz, h, lds_wave);
 
         // ---- head: 4 outputs on the 4x4x1 MFMA (16 blocks of 4 points), see pack_head_kernel -------------------------------
         {
             // (WFOLD: `bias` / `wp` walked the per-image constants / weights: the head's own bias and weights are the shared ones)
             const float* head_bias = WFOLD ? a.bias + (size_t)a.n_mats * H : bias;
-#if CNERF_F32_HEAD_LDS
             const f32x4 acc = head_forward<NT>(s_head, head_bias, x.v, lane);
-#else
-            const f32x4* head_wp = WFOLD ? reinterpret_cast<const f32x4*>(a.packed) + ((size_t)NT * a.n_in + (size_t)(a.n_mats - 1) * NT * NT) * TILE4 : wp;
-            const f32x4 acc = head_forward<NT>(head_wp, head_bias, x.v, lane);
-#endif
             if (valid && h == 0) {
                 f32x4 o;
                 if (a.flags & CNERF_F_SIGMOID_RGB) {
@@ -1192,7 +1140,7 @@ template <int NT, bool HAS_RES, bool STORE, bool DROP, bool FOLD = false, int WF
 static hipError_t launch_field_tile(const FieldArgs& a, hipStream_t stream) {
     if (a.n_in < 1 || a.in_level[0] < 0) return hipErrorInvalidValue;      // the lookup prefetch assumes a volume tile first
     const void* fn = (const void*)field_tile_kernel<NT, HAS_RES, STORE, DROP, FOLD, WFOLD>;
-    const int lds_bytes = (CNERF_F32_LOOKUP_DMA && NT >= 4) ? 4 * 32 * 1024 : 0;   // lookup staging of the four waves
+    const int lds_bytes = 0;
     // (per launch, not once per process: the attribute is per device, and a cached flag would be unsynchronised global state)
     if (lds_bytes)
         if (hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)) return e;
@@ -1206,11 +1154,11 @@ static hipError_t launch_field_nt(const FieldArgs& a, hipStream_t stream) {
     // a.act_h set: activation-storing forward of the backward pass; a.drop_scale != 0: dropout (training mode)
     if (a.drop_scale != 0.0f)
         return a.act_h ? launch_field_tile<NT, HAS_RES, true, true>(a, stream) : launch_field_tile<NT, HAS_RES, false, true>(a, stream);
-    if (CNERF_F32_WFOLD && a.fold && a.packed_img && !a.act_h) {      // (which reduction in front of v_sin: wfolded_sine above)
+    if (a.fold && a.packed_img && !a.act_h) {      // (which reduction in front of v_sin: wfolded_sine above)
         if constexpr (HAS_RES) return launch_field_tile<NT, true, false, false, true, 2>(a, stream);
         else return a.freq ? launch_field_tile<NT, false, false, false, true, 1>(a, stream) : launch_field_tile<NT, false, false, false, true, 2>(a, stream);
     }
-    if (CNERF_F32_FOLD && a.fold && !a.act_h) return launch_field_tile<NT, HAS_RES, false, false, true>(a, stream);
+    if (a.fold && !a.act_h) return launch_field_tile<NT, HAS_RES, false, false, true>(a, stream);
     return a.act_h ? launch_field_tile<NT, HAS_RES, true, false>(a, stream) : launch_field_tile<NT, HAS_RES, false, false>(a, stream);
 }
 

@@ -94,7 +94,6 @@ def make_cfg(net, B, vols, R=1, S=2, fov=30.0, ray_start=0.0, ray_end=1.0, noise
     flags |= L.F_SOFTPLUS if clamp_mode == "softplus" else 0
     flags |= L.F_SIGMOID_RGB if net.spec.sigmoid_rgb else 0
     flags |= L.F_INPUT_XYZ if net.spec.input == "feat_xyz" else 0
-    flags |= L.F_PAIRED_WAVES if getattr(net, "paired_waves", False) else 0      # experimental kernel variant (see include/cnerf.h)
     cfg.flags = flags
     cfg.precision = L.PREC_CODE[precision if precision is not None else precision_of(net)]
     if philox is not None:            # (seed, offset): draws without a tensor are generated in the kernels

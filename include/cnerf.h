@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define CNERF_ABI_VERSION 5
+#define CNERF_ABI_VERSION 6
 
 #define CNERF_OK 0
 #define CNERF_EINVAL (-22)  /* bad argument / unsupported shape (message via cnerf_last_error) */
@@ -39,8 +39,8 @@ extern "C" {
 #define CNERF_F_SOFTPLUS (1u << 3)     /* clamp_mode == "softplus" (else "relu"), volumetric_rendering.py:41-44 */
 #define CNERF_F_SIGMOID_RGB (1u << 4)  /* siren.py:1227-1234  sigmoid on channels 0..2 of the head */
 #define CNERF_F_INPUT_XYZ (1u << 5)    /* siren.py:1158  layer 0 sees features || world xyz (TALLSIREN_dgx) */
-#define CNERF_F_PAIRED_WAVES (1u << 6) /* experimental, precisions fp16x3 / fp16: the two-waves-per-tile variant of the field kernel
-                                          (field_h3p_kernel; same results to rounding, measured slower: DESIGN.md section 5) */
+#define CNERF_F_RESERVED6 (1u << 6)    /* reserved (ABI v4-v5: selected an experimental kernel variant that was measured slower and
+                                          removed in v6); ignored */
 
 /* cnerf_cfg.precision */
 #define CNERF_PREC_FP32 0   /* v_mfma_f32_32x32x2_f32: exact fp32 fmaf chains */

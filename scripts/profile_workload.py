@@ -36,14 +36,15 @@ with torch.no_grad():
         print("ok", float(px.mean()), float(dp.mean()), "points per field launch", B * R * R * S)
         sys.exit(0)
     fcl = ops.channel_last(fvol)
-    pts = torch.cat([aux["coarse_points"].reshape(B, -1, 3), aux["fine_points"].reshape(B, -1, 3)], 1).contiguous()
+    pts = [aux[k].reshape(B, -1, 3).contiguous() for k in ("coarse_points", "fine_points")]   # one lookup launch per field pass
     allz = torch.cat([aux["fine_z"], aux["coarse_z"]], -1)
     allrs = torch.cat([aux["fine_rgb_sigma"], aux["coarse_rgb_sigma"]], -2)
     idx = aux["sort_idx"].long()
     zs = torch.gather(allz, -1, idx).reshape(B * R * R, 2 * S).contiguous()
     rss = torch.gather(allrs, -2, idx.unsqueeze(-1).expand(-1, -1, -1, 4)).reshape(B * R * R, 2 * S, 4).contiguous()
     for _ in range(calls):
-        ops.gather_features(gen.siren, fcl, pts)
+        for p in pts:
+            ops.gather_features(gen.siren, fcl, p, R, S)
         ops.composite(rss, zs, None, 0.0, "relu", True, False)
 torch.cuda.synchronize()
-print("ok", float(px.mean()), float(dp.mean()), "points per field launch", B * R * R * S, "gather points", pts.shape[0] * pts.shape[1])
+print("ok", float(px.mean()), float(dp.mean()), "points per field launch", B * R * R * S, "gather points per launch", pts[0].shape[0] * pts[0].shape[1])

