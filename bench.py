@@ -354,15 +354,23 @@ def gan_step_leg(args, dev, rank, world, dist, batch, precision, backward_precis
     three networks wrapped in DDP over the job's process group -- RCCL on the GPU box, also for a single rank -- on this rank's own
     synthetic batch; the reference's counterpart is train.py:36-44 + utils.py:322-352,621-842.  Returns the step time (max over
     ranks), its split into phases on rank 0 (events on torch's stream), and what DDP all-reduced per optimizer step (communication
-    hooks: calls = buckets, bytes, rounds).  MIOpen stays in immediate mode (its kernel search takes minutes; train.py runs it)."""
+    hooks: calls = buckets, bytes, rounds)."""
     import cnerf_amd
     from cnerf_amd import ops
     from cnerf_amd.training import GanTrainer, default_metadata
     from cnerf_amd.training.gan_step import PhaseTimer, synthetic_sample
+    from cnerf_amd.training.miopen_db import use_shipped_db
+    if not stub and not args.no_miopen_db:
+        use_shipped_db()
+        # FAST find mode: a problem the database knows gets its recorded solver, one it does not falls back to immediate mode -- never
+        # a minutes-long search inside the benchmark
+        os.environ.setdefault("MIOPEN_FIND_MODE", "2")
     R, S = args.img_size, args.num_steps
     md = default_metadata(R, S, batch, 1, args.variant, args.hidden)
     md["discriminator"] = "CCSDiscriminator"               # the "sgdiscriminator" of BASELINE config 3
-    md["render_precision"], md["backward_precision"], md["miopen_find"] = precision, backward_precision, False
+    # MIOpen find mode answered from the find results shipped with the repo (training/miopen_db.py); a shape they do not cover is
+    # searched on the spot (minutes) -- `--no-miopen-db` keeps immediate mode instead (no search, 8x slower convolutions)
+    md["render_precision"], md["backward_precision"], md["miopen_find"] = precision, backward_precision, not stub and not args.no_miopen_db
     modules = None
     if stub:
         md["unet"].update(f_maps=8, num_levels=2)
@@ -622,6 +630,7 @@ def main():
     ap.add_argument("--no-fast-path", action="store_true", help="skip the secondary fp16x3 measurement")
     ap.add_argument("--no-train-step", action="store_true", help="skip the secondary forward + backward measurement")
     ap.add_argument("--no-gan-step", action="store_true", help="skip the GAN training step legs (train_step_ddp, gan_step)")
+    ap.add_argument("--no-miopen-db", action="store_true", help="GAN step legs: MIOpen immediate mode instead of find mode over the shipped find results")
     ap.add_argument("--cpu-reps", type=int, default=2)
     ap.add_argument("--device", default="cuda", choices=["cuda", "cpu"], help="cpu: launcher test with a stand-in step (no measurement)")
     args = ap.parse_args()

@@ -36,6 +36,15 @@ class FieldParams(C.Structure):
                 ("map_w1", C.c_void_p), ("map_b1", C.c_void_p), ("map_w2", C.c_void_p), ("map_b2", C.c_void_p)]
 
 
+class FieldParamGrads(C.Structure):
+    _fields_ = [("w", C.c_void_p * MAX_LAYERS), ("b", C.c_void_p * MAX_LAYERS), ("w2", C.c_void_p * MAX_LAYERS),
+                ("b2", C.c_void_p * MAX_LAYERS), ("w_final", C.c_void_p), ("b_final", C.c_void_p)]
+
+
+class Saved(C.Structure):
+    _fields_ = [("coarse_rgb_sigma", C.c_void_p), ("coarse_z", C.c_void_p), ("fine_rgb_sigma", C.c_void_p), ("fine_z", C.c_void_p)]
+
+
 class Rng(C.Structure):
     _fields_ = [("u_strat", C.c_void_p), ("eps_coarse", C.c_void_p), ("u_fine", C.c_void_p), ("eps_final", C.c_void_p),
                 ("fine_z", C.c_void_p), ("drop_coarse", C.c_void_p), ("drop_fine", C.c_void_p)]
@@ -84,6 +93,10 @@ PROTOTYPES = {
     "cnerf_pack_field_chain16": (C.c_int, [C.POINTER(Cfg), C.POINTER(FieldParams), C.c_void_p, C.c_void_p]),
     "cnerf_field_backward16": (C.c_int, [C.POINTER(Cfg), C.c_uint32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(Volumes)] +
                                [C.c_void_p] * 16 + [C.POINTER(Volumes), C.c_void_p]),
+    "cnerf_backward_workspace_bytes": (C.c_int, [C.POINTER(Cfg), C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_size_t)]),
+    "cnerf_render_backward": (C.c_int, [C.POINTER(Cfg), C.c_int32, C.c_int32, C.POINTER(Volumes), C.POINTER(FieldParams), C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Rng), C.POINTER(Saved), C.POINTER(Aux), C.c_void_p, C.c_void_p,
+                                        C.POINTER(FieldParamGrads), C.c_void_p, C.c_void_p, C.POINTER(Volumes), C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 B16_STORE, B16_DRY, B16_CHAIN = 1, 2, 4
 

@@ -766,12 +766,13 @@ int cnerf_pack_field_chain16(const cnerf_cfg* cfg, const cnerf_field_params* p, 
     return CNERF_OK;
 }
 
-int cnerf_field_backward16(const cnerf_cfg* cfg, uint32_t mode, int32_t group_step, int32_t pass, int32_t image0, int32_t n_images,
-                           const cnerf_volumes* vols, const float* packed, const void* packed16, const float* freq,
-                           const float* phase, const float* cam2world, const float* u_strat, const float* fine_z,
-                           const float* grad_rgb_sigma, const float* saved_rgb_sigma, void* act_feat16, void* act_h16, void* act_c16,
-                           void* act_g16, void* act_go16, const float* scales, uint32_t* gmax, const cnerf_grad_volumes* grad_vols,
-                           void* stream_) {
+namespace {
+int field_backward16_impl(const cnerf_cfg* cfg, uint32_t mode, int32_t group_step, int32_t pass, int32_t image0, int32_t n_images,
+                          const cnerf_volumes* vols, const float* packed, const void* packed16, const float* freq,
+                          const float* phase, const float* cam2world, const float* u_strat, const float* fine_z,
+                          const float* grad_rgb_sigma, const float* saved_rgb_sigma, void* act_feat16, void* act_h16, void* act_c16,
+                          void* act_g16, void* act_go16, const float* scales, uint32_t* gmax, const cnerf_grad_volumes* grad_vols,
+                          uint32_t* sat, float* dfeat, void* stream_) {
     g_err[0] = 0;
     if (int rc = check_cfg(cfg, true)) return rc;
     Chain16Layout l;
@@ -826,14 +827,241 @@ int cnerf_field_backward16(const cnerf_cfg* cfg, uint32_t mode, int32_t group_st
     fa.saved_out = saved_rgb_sigma ? saved_rgb_sigma + (size_t)image0 * npi * 4 : nullptr;
     const float* winv = (const float*)(base16 + l.winv_off);
     if (mode & CNERF_B16_DRY) {
-        if (hipError_t e = launch_chain16(fa, cfg->H, base16, base16 + l.head_off, winv, scales, act_c16, nullptr, nullptr, gmax, l.n_mats, 1,
+        if (hipError_t e = launch_chain16(fa, cfg->H, base16, base16 + l.head_off, winv, scales, act_c16, nullptr, nullptr, gmax, nullptr, nullptr, l.n_mats, 1,
                                           group_step < 1 ? 1 : group_step, stream))
             return hip_fail(e, "chain16 (dry run)");
     }
     if (mode & CNERF_B16_CHAIN) {
-        if (hipError_t e = launch_chain16(fa, cfg->H, base16, base16 + l.head_off, winv, scales, act_c16, act_g16, act_go16, nullptr, l.n_mats, 0, 1,
+        // dfeat given: the chain stores d loss / d (layer-0 input) per point and the volume scatter runs as its own kernel, patch by
+        // patch with coinciding corners pre-reduced in LDS (bwd16.hip, scatter_patch_kernel); else the chain scatters point by point
+        if (hipError_t e = launch_chain16(fa, cfg->H, base16, base16 + l.head_off, winv, scales, act_c16, act_g16, act_go16, nullptr, sat, dfeat, l.n_mats, 0, 1,
                                           stream))
             return hip_fail(e, "chain16");
+        if (dfeat)
+            if (hipError_t e = launch_scatter_patch(fa, dfeat, stream)) return hip_fail(e, "scatter_patch");
+    }
+    return CNERF_OK;
+}
+}  // namespace
+
+int cnerf_field_backward16(const cnerf_cfg* cfg, uint32_t mode, int32_t group_step, int32_t pass, int32_t image0, int32_t n_images,
+                           const cnerf_volumes* vols, const float* packed, const void* packed16, const float* freq,
+                           const float* phase, const float* cam2world, const float* u_strat, const float* fine_z,
+                           const float* grad_rgb_sigma, const float* saved_rgb_sigma, void* act_feat16, void* act_h16, void* act_c16,
+                           void* act_g16, void* act_go16, const float* scales, uint32_t* gmax, const cnerf_grad_volumes* grad_vols,
+                           void* stream_) {
+    return field_backward16_impl(cfg, mode, group_step, pass, image0, n_images, vols, packed, packed16, freq, phase, cam2world, u_strat, fine_z,
+                                 grad_rgb_sigma, saved_rgb_sigma, act_feat16, act_h16, act_c16, act_g16, act_go16, scales, gmax, grad_vols, nullptr,
+                                 nullptr, stream_);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// the whole backward in one call
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+// Workspace of cnerf_render_backward, carved in this order (every piece 256-byte aligned).  n = images_per_chunk * points per
+// image (fp32 backward: row-major fp32 chunk matrices), T = images_per_chunk * tiles per image (fp16 backward: TB16 blocks).
+struct BackwardLayout {
+    size_t gc, gf;                                   // d loss / d rgb_sigma of the coarse / fine samples, whole call
+    size_t a_feat, a_h, a_c, a_g, a_go;              // chunk buffers (a_feat / a_h / a_c absent when the forward kept its activations)
+    size_t gmax, scales;                             // fp16: sampled maxima (n_mats + 1 uint32), {S, 1/S} pairs (n_mats + 1)
+    size_t dwarg, cs, dwh, csh;                      // per-image reductions of one matrix: (cnt, H, 32 * max tiles), (cnt, H), (cnt, 4, H), (cnt, 4)
+    size_t dfeat;                                    // fp16: d loss / d (layer-0 input) per point, (n, 32 * n_in) fp32, between the chain and the scatter
+    size_t total;
+    int n_mats, n_in, k0;
+};
+int backward_layout(const cnerf_cfg* c, int bprec, int cnt, bool have_act16, BackwardLayout& L) {
+    if (bprec != CNERF_PREC_FP32 && bprec != CNERF_PREC_FP16) return fail(CNERF_EINVAL, "render_backward: backward_precision must be CNERF_PREC_FP32 or CNERF_PREC_FP16");
+    if (c->layer_kind[0] == CNERF_LAYER_PFILM)
+        return fail(CNERF_ENOSYS, "render_backward: the per-point FiLM family finishes its mapping-MLP gradients with library GEMMs on the host "
+                                  "(cnerf_field_backward + cnerf_weight_grad + cnerf_scatter_features)");
+    if (cnt < 1 || cnt > c->B) return fail(CNERF_EINVAL, "render_backward: images_per_chunk=%d out of [1,B]", cnt);
+    if (have_act16 && (bprec != CNERF_PREC_FP16 || cnt != c->B)) return fail(CNERF_EINVAL, "render_backward: kept activations need the fp16 backward and images_per_chunk = B");
+    if (bprec == CNERF_PREC_FP16 && c->precision != CNERF_PREC_FP16X3) return fail(CNERF_EINVAL, "render_backward: the fp16 backward re-runs the fp16x3 forward (cfg->precision)");
+    const PackedLayout pl = packed_layout(c);
+    L.n_in = pl.n_in;
+    L.k0 = pl.k0;
+    L.n_mats = 0;
+    for (int l = 0; l < c->L; ++l) L.n_mats += c->layer_kind[l] == CNERF_LAYER_RES ? 2 : 1;
+    const size_t H = c->H, NT = H / 32, npi = (size_t)c->R * c->R * c->S, tpi = (npi + 31) / 32;
+    const size_t N = (size_t)c->B * npi, n = (size_t)cnt * npi, T = (size_t)cnt * tpi;
+    const bool hier = c->flags & CNERF_F_HIERARCHICAL;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off += align256(bytes); return o; };
+    L.gc = take(N * 4 * sizeof(float));
+    L.gf = take(hier ? N * 4 * sizeof(float) : 0);
+    if (bprec == CNERF_PREC_FP16) {
+        L.a_feat = take(have_act16 ? 0 : T * L.n_in * 2048);
+        L.a_h = take(have_act16 ? 0 : (size_t)L.n_mats * T * NT * 2048);
+        L.a_c = take(have_act16 ? 0 : (size_t)L.n_mats * T * NT * 2048);
+        L.a_g = take((size_t)L.n_mats * T * NT * 2048);
+        L.a_go = take(T * 2048);
+    } else {
+        L.a_feat = take(n * 32 * L.n_in * sizeof(float));
+        L.a_h = take((size_t)L.n_mats * n * H * sizeof(float));
+        L.a_c = take((size_t)L.n_mats * n * H * sizeof(float));
+        L.a_g = take((size_t)L.n_mats * n * H * sizeof(float));
+        L.a_go = take(n * 4 * sizeof(float));
+    }
+    L.gmax = take((size_t)(L.n_mats + 2) * sizeof(uint32_t));
+    L.scales = take((size_t)2 * (L.n_mats + 1) * sizeof(float));
+    const size_t kmax = 32 * (size_t)(L.n_in > (int)NT ? L.n_in : (int)NT);
+    L.dwarg = take((size_t)cnt * H * kmax * sizeof(float));
+    L.cs = take((size_t)cnt * H * sizeof(float));
+    L.dwh = take((size_t)cnt * 4 * H * sizeof(float));
+    L.csh = take((size_t)cnt * 4 * sizeof(float));
+    L.dfeat = take(bprec == CNERF_PREC_FP16 ? n * 32 * L.n_in * sizeof(float) : 0);
+    L.total = off;
+    return CNERF_OK;
+}
+}  // namespace
+
+int cnerf_backward_workspace_bytes(const cnerf_cfg* cfg, int32_t backward_precision, int32_t images_per_chunk, int32_t have_act16, size_t* bytes) {
+    g_err[0] = 0;
+    if (int rc = check_cfg(cfg, true)) return rc;
+    BackwardLayout L;
+    if (int rc = backward_layout(cfg, backward_precision, images_per_chunk, have_act16 != 0, L)) return rc;
+    if (bytes) *bytes = L.total;
+    return CNERF_OK;
+}
+
+int cnerf_render_backward(const cnerf_cfg* cfg, int32_t bprec, int32_t cnt_max, const cnerf_volumes* vols, const cnerf_field_params* P,
+                          const float* packed, const void* packed_bwd, const float* freq, const float* phase, const float* cam2world,
+                          const cnerf_rng* rng, const cnerf_saved* saved, const cnerf_aux* kept, const float* grad_pixels,
+                          const float* grad_depth, const cnerf_field_param_grads* G, float* grad_freq, float* grad_phase,
+                          const cnerf_grad_volumes* grad_vols, uint32_t* saturated, void* workspace, void* stream_) {
+    g_err[0] = 0;
+    if (int rc = check_cfg(cfg, true)) return rc;
+    const bool have_act16 = kept && kept->act16[0].h;
+    BackwardLayout L;
+    if (int rc = backward_layout(cfg, bprec, cnt_max, have_act16, L)) return rc;
+    if (!vols || !P || !packed || !packed_bwd || !cam2world || !saved || !grad_pixels || !G || !grad_vols || !workspace)
+        return fail(CNERF_EINVAL, "render_backward: NULL argument");
+    const bool hier = cfg->flags & CNERF_F_HIERARCHICAL;
+    if (!saved->coarse_rgb_sigma || !saved->coarse_z || (hier && (!saved->fine_rgb_sigma || !saved->fine_z)))
+        return fail(CNERF_EINVAL, "render_backward: saved rgb_sigma / z of the forward are incomplete");
+    const PackedLayout pl = packed_layout(cfg);
+    if (pl.n_film && (!freq || !phase || !grad_freq || !grad_phase)) return fail(CNERF_EINVAL, "render_backward: FiLM layers need freq, phase and their gradient buffers");
+    static const cnerf_rng no_rng = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (!rng) rng = &no_rng;
+    hipStream_t stream = (hipStream_t)stream_;
+    const int H = cfg->H, NT = H / 32, B = cfg->B;
+    const long long npi = (long long)cfg->R * cfg->R * cfg->S, tpi = (npi + 31) / 32;
+    char* ws = (char*)workspace;
+    float* gc = (float*)(ws + L.gc);
+    float* gf = hier ? (float*)(ws + L.gf) : nullptr;
+
+    // 1. d(pixels, depth) -> d(rgb_sigma) of every coarse / fine sample
+    if (int rc = cnerf_merge_composite_backward(cfg, saved->coarse_rgb_sigma, saved->coarse_z, saved->fine_rgb_sigma, saved->fine_z,
+                                                cfg->noise_std != 0.0f ? rng->eps_final : nullptr, grad_pixels, grad_depth, gc, gf, stream_))
+        return rc;
+
+    // the matrices in slab order (a residual block: fc1, fc2), their kinds and gradient buffers
+    const float *Wm[2 * CNERF_MAX_LAYERS], *bm[2 * CNERF_MAX_LAYERS];
+    float *dWm[2 * CNERF_MAX_LAYERS], *dbm[2 * CNERF_MAX_LAYERS];
+    int film_of[2 * CNERF_MAX_LAYERS];
+    int nm = 0, nfilm = 0;
+    for (int l = 0; l < cfg->L; ++l) {
+        const bool res = cfg->layer_kind[l] == CNERF_LAYER_RES;
+        if (!P->w[l] || !P->b[l] || (res && (!P->w2[l] || !P->b2[l]))) return fail(CNERF_EINVAL, "render_backward: parameters of layer %d are NULL", l);
+        Wm[nm] = P->w[l]; bm[nm] = P->b[l]; dWm[nm] = G->w[l]; dbm[nm] = G->b[l];
+        film_of[nm] = cfg->layer_kind[l] == CNERF_LAYER_FILM ? nfilm++ : -1;
+        ++nm;
+        if (res) {
+            Wm[nm] = P->w2[l]; bm[nm] = P->b2[l]; dWm[nm] = G->w2[l]; dbm[nm] = G->b2[l];
+            film_of[nm] = -1;
+            ++nm;
+        }
+    }
+    const int film_stride = pl.n_film * H;
+    float* dwarg = (float*)(ws + L.dwarg);
+    float* cs = (float*)(ws + L.cs);
+    float* dwh = (float*)(ws + L.dwh);
+    float* csh = (float*)(ws + L.csh);
+    uint32_t* gmax = (uint32_t*)(ws + L.gmax);
+    float* scales = (float*)(ws + L.scales);
+    void* a_g = ws + L.a_g;
+    void* a_go = ws + L.a_go;
+    if (bprec == CNERF_PREC_FP16)        // only channels 0..3 of a row are ever written: the rest must read as zero
+        if (hipError_t e = hipMemsetAsync(a_go, 0, (size_t)cnt_max * tpi * 2048, stream)) return hip_fail(e, "memset");
+
+    // reduce one matrix' per-image sums into the parameter gradients (and dfreq / dphase of the chunk's images)
+    auto reduce_matrix = [&](int m, int cnt, int b0, int ld) -> int {
+        const int k_real = m == 0 ? L.k0 : H;
+        const bool film = film_of[m] >= 0;
+        const size_t foff = film ? (size_t)b0 * film_stride + (size_t)film_of[m] * H : 0;
+        if (hipError_t e = launch_param_reduce(cnt, H, ld, k_real, dwarg, cs, film ? freq + foff : nullptr, film_stride, Wm[m], bm[m], dWm[m], dbm[m],
+                                               film ? grad_freq + foff : nullptr, film ? grad_phase + foff : nullptr, stream))
+            return hip_fail(e, "param_reduce");
+        return CNERF_OK;
+    };
+
+    for (int pass = 0; pass < (hier ? 2 : 1); ++pass) {
+        const float* g_out = pass ? gf : gc;
+        const float* s_out = pass ? saved->fine_rgb_sigma : saved->coarse_rgb_sigma;
+        const uint8_t* drop = pass ? rng->drop_fine : rng->drop_coarse;
+        for (int b0 = 0; b0 < B; b0 += cnt_max) {
+            const int cnt = b0 + cnt_max <= B ? cnt_max : B - b0;
+            if (bprec == CNERF_PREC_FP16) {
+                const long long T = (long long)cnt * tpi;
+                void* a_feat = have_act16 ? kept->act16[pass].feat : (void*)(ws + L.a_feat);
+                void* a_h = have_act16 ? kept->act16[pass].h : (void*)(ws + L.a_h);
+                void* a_c = have_act16 ? kept->act16[pass].c : (void*)(ws + L.a_c);
+                if (have_act16 && (!a_feat || !a_h || !a_c)) return fail(CNERF_EINVAL, "render_backward: act16 of pass %d is incomplete", pass);
+                // scales: ones for the matrices during the dry run, the head gradient's from max |d loss / d rgb_sigma| of the chunk
+                if (hipError_t e = hipMemsetAsync(gmax, 0, (size_t)(L.n_mats + 2) * sizeof(uint32_t), stream)) return hip_fail(e, "memset");
+                if (hipError_t e = launch_absmax_bits(g_out + (size_t)b0 * npi * 4, (long long)cnt * npi * 4, gmax + L.n_mats + 1, stream)) return hip_fail(e, "absmax");
+                if (hipError_t e = launch_pow2_scales(gmax + L.n_mats + 1, 1, scales + 2 * L.n_mats, stream)) return hip_fail(e, "pow2_scales");
+                for (int m = 0; m < L.n_mats; ++m)
+                    if (hipError_t e = launch_fill(scales + 2 * m, 1.0f, 2, stream)) return hip_fail(e, "fill");
+                const long long groups = (long long)cnt * ((tpi + 3) / 4);
+                long long step = groups / 2048;                       // dry-run sampling: every 16th tile group once there are plenty
+                step = step < 1 ? 1 : (step > 16 ? 16 : step);
+                if (int rc = field_backward16_impl(cfg, (have_act16 ? 0u : CNERF_B16_STORE) | CNERF_B16_DRY, (int)step, pass, b0, cnt, vols, packed, packed_bwd,
+                                                   freq, phase, cam2world, rng->u_strat, saved->fine_z, g_out, s_out, a_feat, a_h, a_c, a_g, a_go, scales, gmax,
+                                                   grad_vols, nullptr, nullptr, stream_))
+                    return rc;
+                if (hipError_t e = launch_pow2_scales(gmax, L.n_mats, scales, stream)) return hip_fail(e, "pow2_scales");
+                if (int rc = field_backward16_impl(cfg, CNERF_B16_CHAIN, 1, pass, b0, cnt, vols, packed, packed_bwd, freq, phase, cam2world, rng->u_strat,
+                                                   saved->fine_z, g_out, s_out, a_feat, a_h, a_c, a_g, a_go, scales, gmax, grad_vols, saturated,
+                                                   (float*)(ws + L.dfeat), stream_))
+                    return rc;
+                const size_t slab = (size_t)T * NT * 2048;             // bytes per matrix in a_h / a_g
+                for (int m = 0; m < L.n_mats; ++m) {
+                    const int x_ct = m == 0 ? L.n_in : NT;
+                    const void* X = m == 0 ? a_feat : (const void*)((const char*)a_h + (size_t)(m - 1) * slab);
+                    if (hipError_t e = hipMemsetAsync(dwarg, 0, (size_t)cnt * H * 32 * x_ct * sizeof(float), stream)) return hip_fail(e, "memset");
+                    if (hipError_t e = hipMemsetAsync(cs, 0, (size_t)cnt * H * sizeof(float), stream)) return hip_fail(e, "memset");
+                    if (int rc = cnerf_weight_grad16(cnt, tpi, H, NT, x_ct, (const char*)a_g + (size_t)m * slab, X, dwarg, cs, scales + 2 * m + 1, stream_)) return rc;
+                    if (int rc = reduce_matrix(m, cnt, b0, 32 * x_ct)) return rc;
+                }
+                if (hipError_t e = hipMemsetAsync(dwh, 0, (size_t)cnt * 4 * H * sizeof(float), stream)) return hip_fail(e, "memset");
+                if (hipError_t e = hipMemsetAsync(csh, 0, (size_t)cnt * 4 * sizeof(float), stream)) return hip_fail(e, "memset");
+                if (int rc = cnerf_weight_grad16(cnt, tpi, 4, 1, NT, a_go, (const char*)a_h + (size_t)(L.n_mats - 1) * slab, dwh, csh, scales + 2 * L.n_mats + 1, stream_))
+                    return rc;
+                if (hipError_t e = launch_param_reduce(cnt, 4, H, H, dwh, csh, nullptr, 0, nullptr, nullptr, G->w_final, G->b_final, nullptr, nullptr, stream))
+                    return hip_fail(e, "param_reduce (head)");
+            } else {
+                const size_t n = (size_t)cnt * npi;
+                float* a_feat = (float*)(ws + L.a_feat);
+                float* a_h = (float*)(ws + L.a_h);
+                float* a_c = (float*)(ws + L.a_c);
+                if (int rc = cnerf_field_backward(cfg, pass, b0, cnt, vols, packed, (const float*)packed_bwd, freq, phase, cam2world, rng->u_strat, saved->fine_z,
+                                                  g_out, s_out, a_feat, a_h, a_c, (float*)a_g, (float*)a_go, grad_vols, drop, stream_))
+                    return rc;
+                for (int m = 0; m < L.n_mats; ++m) {
+                    const int K = m == 0 ? 32 * L.n_in : H;
+                    const float* X = m == 0 ? a_feat : a_h + (size_t)(m - 1) * n * H;
+                    if (hipError_t e = hipMemsetAsync(dwarg, 0, (size_t)cnt * H * K * sizeof(float), stream)) return hip_fail(e, "memset");
+                    if (hipError_t e = hipMemsetAsync(cs, 0, (size_t)cnt * H * sizeof(float), stream)) return hip_fail(e, "memset");
+                    if (int rc = cnerf_weight_grad(cnt, npi, H, K, (const float*)a_g + (size_t)m * n * H, X, dwarg, cs, stream_)) return rc;
+                    if (int rc = reduce_matrix(m, cnt, b0, K)) return rc;
+                }
+                if (G->w_final && G->b_final)
+                    if (hipError_t e = launch_head_grad32((const float*)a_go, a_h + (size_t)(L.n_mats - 1) * n * H, (long long)n, H, G->w_final, G->b_final, stream))
+                        return hip_fail(e, "head_grad32");
+            }
+        }
     }
     return CNERF_OK;
 }

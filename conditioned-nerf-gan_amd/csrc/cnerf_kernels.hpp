@@ -177,6 +177,11 @@ hipError_t launch_scatter(const GatherArgs& a, const float* grad_feat, float* gr
 
 hipError_t launch_weight_grad(int cnt, long long npi, int H, int K, const float* G, const float* X, float* dW, float* colsum,
                               hipStream_t stream);
+hipError_t launch_param_reduce(int cnt, int rows, int ld, int k_real, const float* dWarg, const float* cs, const float* freq, int film_stride,
+                               const float* W, const float* bias, float* dW, float* db, float* g_freq, float* g_phase, hipStream_t stream);
+hipError_t launch_head_grad32(const float* go, const float* x, long long n, int H, float* dW, float* db, hipStream_t stream);
+hipError_t launch_absmax_bits(const float* v, long long n, uint32_t* slot, hipStream_t stream);
+hipError_t launch_pow2_scales(const uint32_t* gmax_bits, int n, float* scales, hipStream_t stream);
 
 // bwd16.hip
 hipError_t launch_pack_t16(const float* w, int n_rows_w, int n_cols_w, int n_cols_real, int OT_padded, void* dst, float* winv_slot, uint32_t* wmax_slot,
@@ -184,7 +189,8 @@ hipError_t launch_pack_t16(const float* w, int n_rows_w, int n_cols_w, int n_col
 hipError_t launch_col_abs_sum_max(const float* w, int n_rows, int n_cols, float* slot, hipStream_t stream);
 hipError_t launch_pack_head_t16(const float* w, int H, void* dst, float* winv_slot, uint32_t* wmax_slot, hipStream_t stream);
 hipError_t launch_chain16(const FieldArgs& f, int H, const void* units, const void* head_t, const float* winv, const float* scales, const void* cos16,
-                          void* g16, void* go16, unsigned int* gmax, int nslab, int dry, int group_step, hipStream_t stream);
+                          void* g16, void* go16, unsigned int* gmax, unsigned int* sat, float* dfeat, int nslab, int dry, int group_step, hipStream_t stream);
+hipError_t launch_scatter_patch(const FieldArgs& f, const float* dfeat, hipStream_t stream);
 hipError_t launch_weight_grad16(int cnt, long long tiles_per_image, int n_rows, int g_ct, int x_ct, const void* G, const void* X, float* dW,
                                 float* colsum, const float* inv_scale, hipStream_t stream);
 

@@ -170,4 +170,140 @@ hipError_t launch_weight_grad(int cnt, long long npi, int H, int K, const float*
     return hipErrorInvalidValue;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Parameter gradients from the per-image reductions (cnerf_render_backward): what autograd does behind FiLMLayer / SirenLayer
+// (siren.py:146-199) once dWarg[b] = G[b]^T X[b] and cs[b] = column sums of G[b] exist (weight_grad_kernel / weight_grad16_kernel):
+//     dW[i][k] += sum_b f_b[i] dWarg[b][i][k]        db[i] += sum_b f_b[i] cs[b][i]                 (f = 1 without FiLM)
+//     dphase[b][i] += cs[b][i]                       dfreq[b][i] += sum_k W[i][k] dWarg[b][i][k] + bias[i] cs[b][i]
+// One wave per output row i, lanes over k; every output element has one owner: plain read-modify-write, no atomics.
+// ---------------------------------------------------------------------------------------------------------------
+struct ParamReduceArgs {
+    const float* dWarg;   // (cnt, rows, ld)
+    const float* cs;      // (cnt, rows)
+    const float* freq;    // (cnt, film_stride) already offset to this matrix' H-vector of image 0 of the chunk, or null
+    const float* W;       // (rows, k_real) raw weight (dfreq) or null
+    const float* bias;    // (rows) or null
+    float* dW;            // (rows, k_real) or null
+    float* db;            // (rows) or null
+    float* g_freq;        // (cnt, film_stride) offset like freq, or null
+    float* g_phase;
+    int cnt, rows, ld, k_real, film_stride;
+};
+__global__ __launch_bounds__(64) void param_reduce_kernel(ParamReduceArgs a) {
+    const int i = blockIdx.x, lane = threadIdx.x;
+    constexpr int SLOTS = 4;                          // k_real <= 256
+    float dw[SLOTS] = {0.f, 0.f, 0.f, 0.f};
+    float dbi = 0.0f;
+    for (int b = 0; b < a.cnt; ++b) {
+        const float f = a.freq ? a.freq[(size_t)b * a.film_stride + i] : 1.0f;
+        const float c = a.cs[(size_t)b * a.rows + i];
+        const float* row = a.dWarg + ((size_t)b * a.rows + i) * a.ld;
+        float dot = 0.0f;
+#pragma unroll
+        for (int q = 0; q < SLOTS; ++q) {
+            const int k = lane + 64 * q;
+            if (k < a.k_real) {
+                const float v = row[k];
+                dw[q] = __builtin_fmaf(f, v, dw[q]);
+                if (a.g_freq) dot = __builtin_fmaf(a.W[(size_t)i * a.k_real + k], v, dot);
+            }
+        }
+        dbi = __builtin_fmaf(f, c, dbi);
+        if (a.g_freq) {
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) dot += __shfl_xor(dot, d, WAVE);
+            if (lane == 0) {
+                a.g_freq[(size_t)b * a.film_stride + i] += dot + a.bias[i] * c;
+                a.g_phase[(size_t)b * a.film_stride + i] += c;
+            }
+        }
+    }
+    if (a.dW) {
+#pragma unroll
+        for (int q = 0; q < SLOTS; ++q) {
+            const int k = lane + 64 * q;
+            if (k < a.k_real) a.dW[(size_t)i * a.k_real + k] += dw[q];
+        }
+    }
+    if (a.db && lane == 0) a.db[i] += dbi;
+}
+hipError_t launch_param_reduce(int cnt, int rows, int ld, int k_real, const float* dWarg, const float* cs, const float* freq, int film_stride,
+                               const float* W, const float* bias, float* dW, float* db, float* g_freq, float* g_phase, hipStream_t stream) {
+    if (k_real > 256 || rows < 1 || cnt < 1) return hipErrorInvalidValue;
+    ParamReduceArgs a{dWarg, cs, freq, W, bias, dW, db, freq ? g_freq : nullptr, freq ? g_phase : nullptr, cnt, rows, ld, k_real, film_stride};
+    hipLaunchKernelGGL(param_reduce_kernel, dim3((unsigned)rows), dim3(64), 0, stream, a);
+    return hipGetLastError();
+}
+
+// Head of the exact fp32 backward: dW_head (4, H) += go^T x, db_head (4) += column sums of go, over n points; go (n, 4) = d / d
+// head pre-activation, x (n, H) = the last hidden activation, both row-major fp32 (cnerf_field_backward's act_go / act_h).
+// Thread c of a block owns channel c: x[n][c] is a coalesced row read, go[n][0..3] a broadcast; blocks split the points.
+__global__ __launch_bounds__(256) void head_grad32_kernel(const float* __restrict__ go, const float* __restrict__ x, long long n, int H,
+                                                          float* __restrict__ dW, float* __restrict__ db) {
+    const int c = threadIdx.x;
+    const long long per = (n + gridDim.x - 1) / gridDim.x;
+    const long long n0 = (long long)blockIdx.x * per, n1 = n0 + per < n ? n0 + per : n;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f}, cs[4] = {0.f, 0.f, 0.f, 0.f};
+    for (long long p = n0; p < n1; ++p) {
+        const f32x4 g = *reinterpret_cast<const f32x4*>(go + p * 4);
+        const float xv = c < H ? x[p * H + c] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            acc[r] = __builtin_fmaf(g[r], xv, acc[r]);
+            cs[r] += g[r];
+        }
+    }
+    if (c < H)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) atomicAdd(dW + (size_t)r * H + c, acc[r]);
+    if (c == 0)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) atomicAdd(db + r, cs[r]);
+}
+hipError_t launch_head_grad32(const float* go, const float* x, long long n, int H, float* dW, float* db, hipStream_t stream) {
+    if (H > 256 || n < 1) return hipErrorInvalidValue;
+    long long blocks = (n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(head_grad32_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, go, x, n, H, dW, db);
+    return hipGetLastError();
+}
+
+// max |v| of n floats as the bit pattern of a non-negative float (atomicMax on the bits; *slot zeroed by the caller)
+__global__ void absmax_bits_kernel(const float* __restrict__ v, long long n, uint32_t* slot) {
+    float m = 0.0f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(v[i]));
+#pragma unroll
+    for (int d = WAVE / 2; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, WAVE));
+    if ((threadIdx.x & 63) == 0 && m == m) atomicMax(slot, __float_as_uint(m));
+}
+hipError_t launch_absmax_bits(const float* v, long long n, uint32_t* slot, hipStream_t stream) {
+    long long blocks = (n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(absmax_bits_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, v, n, slot);
+    return hipGetLastError();
+}
+
+// {S, 1 / S} per sampled maximum: S = 2^(11 - ceil(log2 max)) -- the maximum lands in (2^10, 2^11], a factor 32 below fp16's
+// largest number for values the sample missed (the chain clamps beyond) -- and 1 where the maximum is 0.
+__global__ void pow2_scales_kernel(const uint32_t* __restrict__ gmax_bits, int n, float* __restrict__ scales) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float g = __uint_as_float(gmax_bits[i]);
+    float S = 1.0f;
+    if (g > 0.0f && g < 3e38f) {
+        int e;
+        const float m = frexpf(g, &e);                 // g = m 2^e, m in [0.5, 1): ceil(log2 g) = e, or e - 1 when g is a power of two
+        const int ce = m == 0.5f ? e - 1 : e;
+        int se = 11 - ce;
+        se = se > 100 ? 100 : (se < -100 ? -100 : se);
+        S = ldexpf(1.0f, se);
+    }
+    scales[2 * i] = S;
+    scales[2 * i + 1] = 1.0f / S;
+}
+hipError_t launch_pow2_scales(const uint32_t* gmax_bits, int n, float* scales, hipStream_t stream) {
+    hipLaunchKernelGGL(pow2_scales_kernel, dim3(1), dim3(64), 0, stream, gmax_bits, n, scales);
+    return n <= 64 ? hipGetLastError() : hipErrorInvalidValue;
+}
+
 }  // namespace cnerf

@@ -5,9 +5,9 @@
 // Replaces fancy_integration (volumetric_rendering.py:18-70), sample_pdf (:297-342) with its call site
 // (generators.py:123-137), the cat/sort/gather merge (generators.py:162-167), the epilogue (generators.py:182-186,
 // distance2depth volumetric_rendering.py:345-356) and F.grid_sample + permute (siren.py:555-571).
-#include <cstdlib>
 #include "cnerf_dev.hpp"
 #include "cnerf_kernels.hpp"
+#include "patch_box.hpp"
 
 namespace cnerf {
 
@@ -558,30 +558,77 @@ __global__ __launch_bounds__(256) void gather_kernel(GatherArgs a) {
     for (long long pt = pr.begin; pt < pr.end; pt += pr.stride) gather_point(a, pt, sub);
 }
 
-// The same lookup with the points of a render visited patch by patch: when the caller says the points are the samples of R x R
-// rays x S depths in ray-major order (GatherArgs::R, S), the 32 points a block handles per iteration are PX x PY neighbouring
-// pixels x PD consecutive depths instead of 32 consecutive samples of ONE ray.  Consecutive samples of a ray are ~1.4 voxels
-// apart and share next to no corner lines; neighbouring pixels are ~0.4 voxel apart at the same depth, so the 256 corner lines a
-// tile asks for are a few dozen distinct ones and the repeats are served by the CU's vector L1 instead of by L2 (the kernel's
-// limiter at 1 KiB per point).  Which point a thread handles never changes what is computed for it: results are bit-identical.
-// Tile order = (image, patch row, patch column, depth slot) with the depth slot innermost, tiles dealt to the blocks of an XCD
-// class in a stride, so the tiles in flight on an XCD at any time are a compact slab of the volume (L2 locality as before).
-template <int PX, int PY, int PD>
-__global__ __launch_bounds__(256) void gather_patch_kernel(GatherArgs a) {
-    static_assert(PX * PY * PD == 32, "a block iteration covers 32 points");
-    const int sub = threadIdx.x & 7, q = threadIdx.x >> 3;
-    const int dx = q % PX, dy = (q / PX) % PY, dd = q / (PX * PY);
-    const int n_ds = a.S / PD, n_pc = a.R / PX, n_pr = a.R / PY;
-    const long long tpi = (long long)n_ds * n_pc * n_pr, total = tpi * a.B;
+// The same lookup with the points of a render visited patch by patch and every distinct corner line fetched ONCE.  When the caller
+// says the points are the samples of R x R rays x S depths in ray-major order (GatherArgs::R, S), a wave takes a patch of 4 x 4
+// neighbouring pixels x 2 consecutive depths (32 points) instead of 32 consecutive samples of one ray: consecutive samples of a ray
+// are ~1.4 voxels apart and share next to no corner lines, neighbouring pixels are ~0.4 voxel apart at the same depth, so the 256
+// corner lines of the patch are 20-40 distinct ones.  Counters of the point-by-point kernel (profiles/r03_gather_counters.md): 1 KiB
+// per point goes through the texture addresser and the vector L1, half of it misses to L2 at 255 cycles average round trip, the L1
+// stalls on pending misses for 42 % of its active cycles -- the kernel is bound by L1 miss handling, with HBM traffic already within
+// 1.2x of compulsory.  Merely visiting the points in patch order did not help (the duplicates are in flight together and each
+// still takes its own trip to L2: 1.23 -> 1.34 ms).  So the duplicates are removed before they are requested: the distinct voxels
+// of the patch are numbered (patch_box.hpp), each line is loaded once into LDS (8 lanes x 16 bytes per line, 8 lines per wave
+// instruction), and the 8 corners of every point are read from there (ds_read_b128, 128 B/clk).  The arithmetic per point is
+// gather_point's, operand for operand: results are bit-identical.  Tiles that are not reducible fall back to gather_point.
+__global__ __launch_bounds__(256) void gather_box_kernel(GatherArgs a) {
+    __shared__ f32x4 s_line[4][PB_SLOTS * 8];       // one 128-byte line per distinct voxel
+    __shared__ int s_key[4][32 * 8];
+    __shared__ float s_w[4][32 * 8];
+    __shared__ int s_slot[4][256];
+    __shared__ int s_vox[4][PB_SLOTS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, sub = lane & 7, q8 = lane >> 3;
+    f32x4* line = s_line[wave];
+    int* key = s_key[wave];
+    float* sw = s_w[wave];
+    int* slot = s_slot[wave];
+    int* svox = s_vox[wave];
+    const long long tpi = a.n_per_image / 32, total = tpi * a.B;      // (patch shapes: n_per_image is a multiple of 32)
     const int cls = blockIdx.x & 7, idx_in_cls = blockIdx.x >> 3;
     const int blk_per_cls = (gridDim.x + 7 - cls) / 8;
-    const long long end = total * (cls + 1) / 8;
-    for (long long t = total * cls / 8 + idx_in_cls; t < end; t += blk_per_cls) {
-        const long long b = t / tpi;
-        const int r = (int)(t - b * tpi);
-        const int ds = r % n_ds, pc = (r / n_ds) % n_pc, prow = r / (n_ds * n_pc);
-        const int pixel = (prow * PY + dy) * a.R + pc * PX + dx;
-        gather_point(a, b * a.n_per_image + (long long)pixel * a.S + ds * PD + dd, sub);
+    const long long t_end = total * (cls + 1) / 8;
+    for (long long t0 = total * cls / 8 + (long long)idx_in_cls * 4; t0 < t_end; t0 += (long long)blk_per_cls * 4) {
+        const long long t = t0 + wave;
+        if (t >= t_end) continue;                                     // wave-uniform
+        const long long b = t / tpi, ti = t - b * tpi;
+        const long long pt_j = b * a.n_per_image + patch_point(true, ti, j, a.R, a.S);
+        const float* pj = a.points + pt_j * 3;
+        Corner8 cr;
+        int lo[3], hi[3];
+        trilinear_corners(__builtin_nontemporal_load(pj), __builtin_nontemporal_load(pj + 1), __builtin_nontemporal_load(pj + 2), a.half_voxel, a.V, cr, lo, hi);
+        const PatchBox pb = patch_box_build<false>(cr, lo, hi, true, a.V, lane, key, sw, slot, svox);
+        const float* vol = a.fvol + (size_t)b * a.V * a.V * a.V * 32 + 4 * sub;
+        if (!pb.reducible) {            // grazing rays / very fine grids: point by point
+#pragma unroll 1
+            for (int it = 0; it < 4; ++it) gather_point(a, b * a.n_per_image + patch_point(true, ti, it * 8 + q8, a.R, a.S), sub);
+            pb_wave_sync();
+            continue;
+        }
+        // every distinct line once: 8 lines per wave instruction, 8 lanes x 16 bytes each
+        for (int s0 = 0; s0 < pb.U; s0 += 8) {
+            const int sl = s0 + q8;
+            if (sl < pb.U) line[sl * 8 + sub] = *reinterpret_cast<const f32x4*>(vol + (size_t)svox[sl] * 32);
+        }
+        pb_wave_sync();
+#pragma unroll 1
+        for (int it = 0; it < 4; ++it) {
+            const int p = it * 8 + q8;
+            f32x4 q[8];
+            float w[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                q[k] = line[slot[key[p * 8 + k]] * 8 + sub];
+                w[k] = sw[p * 8 + k];
+            }
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] = acc[e] + q[k][e] * w[k];
+            const long long pt = b * a.n_per_image + patch_point(true, ti, p, a.R, a.S);
+            __builtin_nontemporal_store(acc, reinterpret_cast<f32x4*>(a.feat + pt * 32 + 4 * sub));
+        }
+        pb_wave_sync();                 // the next tile overwrites the wave's tables
     }
 }
 
@@ -649,27 +696,17 @@ hipError_t launch_transpose_cl(int B, int C, int V, const float* src, float* dst
     hipLaunchKernelGGL(transpose_cl_kernel, grid, dim3(256), 0, stream, src, dst, V3, C, to_channel_last ? 1 : 0);
     return hipGetLastError();
 }
-template <int PX, int PY, int PD>
-static bool try_gather_patch(const GatherArgs& a, hipStream_t stream) {
-    if (a.R <= 0 || a.S <= 0 || a.R % PX || a.R % PY || a.S % PD || (long long)a.R * a.R * a.S != a.n_per_image) return false;
-    long long blocks = (long long)a.B * (a.R / PX) * (a.R / PY) * (a.S / PD);
-    if (blocks > 256 * 16) blocks = 256 * 16;
-    blocks = (blocks + 7) / 8 * 8;
-    hipLaunchKernelGGL((gather_patch_kernel<PX, PY, PD>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
-    return true;
-}
-
 hipError_t launch_gather(const GatherArgs& a, hipStream_t stream) {
-    // EXPERIMENT SWITCH (to be removed once measured): CNERF_GATHER_TILING = 0 linear, 1: 4x4x2, 2: 8x4x1, 3: 2x2x8, 4: 4x2x4, 5: 8x2x2
-    static const int mode = [] { const char* e = getenv("CNERF_GATHER_TILING"); return e ? atoi(e) : 1; }();
-    bool done = false;
-    if (mode == 1) done = try_gather_patch<4, 4, 2>(a, stream);
-    else if (mode == 2) done = try_gather_patch<8, 4, 1>(a, stream);
-    else if (mode == 3) done = try_gather_patch<2, 2, 8>(a, stream);
-    else if (mode == 4) done = try_gather_patch<4, 2, 4>(a, stream);
-    else if (mode == 5) done = try_gather_patch<8, 2, 2>(a, stream);
-    if (done) return hipGetLastError();
     const long long total = (long long)a.B * a.n_per_image;
+    // a render's samples (R x R rays x S depths, ray-major) whose shape the 4 x 4 x 2 patch divides: patch by patch, distinct lines once
+    if (a.R > 0 && a.S > 0 && a.R % 4 == 0 && a.S % 2 == 0 && (long long)a.R * a.R * a.S == a.n_per_image) {
+        long long blocks = total / 32 / 4;
+        if (blocks > 256 * 12) blocks = 256 * 12;
+        if (blocks < 8) blocks = 8;
+        blocks = (blocks + 7) / 8 * 8;
+        hipLaunchKernelGGL(gather_box_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+        return hipGetLastError();
+    }
     long long blocks = (total + 31) / 32;
     if (blocks > 256 * 16) blocks = 256 * 16;
     blocks = (blocks + 7) / 8 * 8;                    // every XCD class owns an eighth of the points

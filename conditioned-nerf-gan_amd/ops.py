@@ -337,10 +337,10 @@ def pack_field_transposed(net, cfg):
     return packed_t
 
 
-DEBUG_CAPTURE = None            # set to a dict to capture the backward's chunk buffers (scripts/debug_b16.py)
+DEBUG_CAPTURE = None            # set to a dict to capture the chunk buffers of the per-point FiLM backward (debugging)
 PHASE_TIMER = None              # an object with begin() / end(name, start) (training.gan_step.PhaseTimer): RenderFunction.backward
                                 # reports its span as "render_bwd" so that a caller can split an autograd pass (bench.py gan_step)
-ACT_BUDGET_BYTES = 128 << 30    # activation / gradient chunk buffers of the backward (288 GB HBM per GPU: batch 8 at 128x128x64 in one chunk)
+ACT_BUDGET_BYTES = 128 << 30    # chunk buffers of the per-point FiLM backward: at most this much, and MEMORY_FRACTION of what is free
 
 
 def _pfilm_backward(net, o, cfg, levels, cam2world, rng, saved, gc, gf):
@@ -363,7 +363,7 @@ def _pfilm_backward(net, o, cfg, levels, cam2world, rng, saved, gc, gf):
     gvs = volumes_struct([g_level])
     c_rs, c_z, f_rs, f_z, c_pts, f_pts = saved[:6]
     per_image = npi * (32 + 256 + 7 * nl * H + 4) * 4
-    nb = max(1, min(B, ACT_BUDGET_BYTES // per_image))
+    nb = max(1, min(B, int(min(ACT_BUDGET_BYTES, MEMORY_FRACTION * free_device_bytes(dev))) // per_image))
     u_strat = _f32(rng.get("u_strat"))
     act = None
     passes = [(0, gc, c_rs, c_pts)] + ([(1, gf, f_rs, f_pts)] if hier else [])
@@ -453,17 +453,8 @@ def pack_field_chain16(net, cfg):
     return packed16
 
 
-def _pow2_scales(gmax_bits):
-    """Per entry of the sampled maxima (uint32 bit patterns of non-negative floats): {S, 1/S} with S = 2^(11 - ceil(log2 max)) --
-    the sampled maximum lands in (2^10, 2^11], leaving a factor 32 to fp16's largest number for values the sample missed (the
-    kernel clamps beyond that); 1 where the maximum is 0.  Device ops only: no host round trip."""
-    gm = gmax_bits.view(torch.float32)
-    e = torch.ceil(torch.log2(gm.clamp_min(1e-30))).clamp(-100, 100)
-    S = torch.where(gm > 0, torch.exp2(11.0 - e), torch.ones_like(gm))
-    return torch.stack([S, 1.0 / S], -1).reshape(-1).contiguous()
-
-
-RESIDENT_BUDGET_BYTES = 160 << 30    # fp16 activations kept from the forward for the backward (288 GB of HBM per GPU)
+RESIDENT_BUDGET_BYTES = 160 << 30    # fp16 activations kept from the forward for the backward: at most this much (288 GB of HBM per GPU) ...
+RESIDENT_FRACTION = 0.5              # ... and at most this share of the memory that is free when the forward starts
 
 
 def resident_act16(net, levels, B, R, S, hier, dev):
@@ -475,245 +466,115 @@ def resident_act16(net, levels, B, R, S, hier, dev):
     T = B * ((R * R * S + 31) // 32)
     n_pass = 2 if hier else 1
     per_pass = T * 2048 * (n_in + 2 * nslab * NT)
-    if n_pass * per_pass + T * 2048 * (nslab * NT + 1) > RESIDENT_BUDGET_BYTES:
+    if n_pass * per_pass + T * 2048 * (nslab * NT + 1) > min(RESIDENT_BUDGET_BYTES, RESIDENT_FRACTION * free_device_bytes(dev)):
         return None
     f16 = dict(dtype=torch.float16, device=dev)
     return [(torch.empty((T, n_in, 32, 32), **f16), torch.empty((nslab, T, NT, 32, 32), **f16), torch.empty((nslab, T, NT, 32, 32), **f16))
             for _ in range(n_pass)]
 
 
-def _render_backward16(net, o, levels, freq, phase, cam2world, rng, saved, grad_pixels, grad_depth, act16=None):
-    """render_backward with fp16 gradient GEMMs (see include/cnerf.h, "half-precision backward"): per chunk of images the
-    fp16x3 forward is re-run storing x0 / sin / cos as fp16 tile blocks, a sampled dry run of the chain finds each matrix'
-    gradient magnitude, the chain writes d/d(arg) as scaled fp16 tile blocks and scatters d/d(volume), and one fp16-MFMA
-    reduction per matrix forms G^T X and the column sums; dW, db, dfreq, dphase follow from those exactly as in the fp32 path."""
-    B, R, S, hier = o["B"], o["R"], o["S"], o["hier"]
-    dev = cam2world.device
-    cfg = make_cfg(net, B, levels, R, S, o["fov"], o["ray_start"], o["ray_end"], o["noise_std"], hier,
-                   o["white_back"], o["last_back"], o["clamp_mode"], precision="fp16x3", philox=rng.get("philox"))
-    vs = volumes_struct(levels)
-    packed = pack_field(net, cfg)
-    packed16 = pack_field_chain16(net, cfg)
-    H, k0 = int(net.hidden_dim), int(net.input_dim)
-    NT = H // 32
-    n_in = cfg.C // 32 + (1 if net.spec.input == "feat_xyz" else 0)
-    kinds = []                         # one entry per matrix: a residual block contributes fc1 and fc2, both plain-sine slabs
-    for k in net.spec.layers:
-        kinds += ["sine", "sine"] if k == "res" else [k]
-    nslab = len(kinds)
-    npi = R * R * S
-    tpi = (npi + 31) // 32
-    c_rs, c_z, f_rs, f_z = saved[:4]
-    gc = torch.empty_like(c_rs)
-    gf = torch.empty_like(f_rs) if hier else None
-    grad_pixels = _f32(grad_pixels)
-    grad_depth = _f32(grad_depth) if grad_depth is not None else None
-    eps_final = _f32(rng.get("eps_final")) if o["noise_std"] != 0 else None
-    L.check(L.lib().cnerf_merge_composite_backward(C.byref(cfg), L.ptr(c_rs), L.ptr(c_z), L.ptr(f_rs) if hier else None,
-                                                   L.ptr(f_z) if hier else None, L.ptr(eps_final), L.ptr(grad_pixels),
-                                                   L.ptr(grad_depth), L.ptr(gc), L.ptr(gf) if hier else None, _stream()),
-            "cnerf_merge_composite_backward")
-    params = net.field_params()
-    Ws = [params[2 * l].detach() for l in range(nslab)]
-    bs = [params[2 * l + 1].detach() for l in range(nslab)]
-    W_head = params[2 * nslab].detach()
-    dW = [torch.zeros_like(w) for w in Ws]
-    db = [torch.zeros_like(b) for b in bs]
-    dW_head = torch.zeros_like(W_head)
-    db_head = torch.zeros(4, dtype=torch.float32, device=dev)
-    n_film = sum(1 for k in kinds if k == "film")
-    g_freq = torch.zeros((B, n_film * H), dtype=torch.float32, device=dev) if n_film else None
-    g_phase = torch.zeros_like(g_freq) if n_film else None
-    grad_levels = [torch.zeros_like(v) for v in levels]
-    gvs = volumes_struct(grad_levels)
+def _field_param_grads_struct(net, grads):
+    """cnerf_field_param_grads over the flat tensor list `grads` (same order as net.field_params(), no mapping MLP)."""
+    gp = L.FieldParamGrads()
+    it = iter(grads)
+    for i, kind in enumerate(net.spec.layers):
+        gp.w[i], gp.b[i] = next(it).data_ptr(), next(it).data_ptr()
+        if kind == "res":
+            gp.w2[i], gp.b2[i] = next(it).data_ptr(), next(it).data_ptr()
+    gp.w_final, gp.b_final = next(it).data_ptr(), next(it).data_ptr()
+    return gp
 
-    per_image = tpi * 2048 * (n_in + 3 * nslab * NT + 1)
-    nb = B if act16 is not None else max(1, min(B, ACT_BUDGET_BYTES // per_image))   # kept activations: all images in one go
-    groups = B * ((tpi + 3) // 4)
-    step = max(1, min(16, groups // 2048))          # dry-run sampling: every 16th tile group once there are plenty
-    u_strat = _f32(rng.get("u_strat"))
-    f16 = dict(dtype=torch.float16, device=dev)
-    act, act_T = None, -1
-    passes = [(0, gc, c_rs)] + ([(1, gf, f_rs)] if hier else [])
-    for pss, g_out, saved_out in passes:
-        for b0 in range(0, B, nb):
-            cnt = min(nb, B - b0)
-            T = cnt * tpi
-            if act16 is not None:          # x0 / sin / cos were kept by the forward; only the gradient buffers are new
-                if act is None:
-                    act = (torch.empty((nslab, T, NT, 32, 32), **f16), torch.zeros((T, 1, 32, 32), **f16))
-                (a_feat, a_h, a_c), (a_g, a_go) = act16[pss], act
-            else:
-                if act_T != T:
-                    act = (torch.empty((T, n_in, 32, 32), **f16), torch.empty((nslab, T, NT, 32, 32), **f16),
-                           torch.empty((nslab, T, NT, 32, 32), **f16), torch.empty((nslab, T, NT, 32, 32), **f16),
-                           torch.zeros((T, 1, 32, 32), **f16))
-                    act_T = T
-                a_feat, a_h, a_c, a_g, a_go = act
-            gmax = torch.zeros(nslab + 1, dtype=torch.int32, device=dev)
-            # the head gradient's scale is known up front: |go'| <= |d loss / d rgb_sigma| (sigmoid' <= 1/4 only shrinks it)
-            go_scale = _pow2_scales(g_out[b0:b0 + cnt].abs().amax().reshape(1).view(torch.int32))
-            scales = torch.cat([torch.ones(2 * nslab, dtype=torch.float32, device=dev), go_scale])
 
-            def call(mode, group_step, scales_t):
-                L.check(L.lib().cnerf_field_backward16(C.byref(cfg), mode, group_step, pss, b0, cnt, C.byref(vs), L.ptr(packed), L.ptr(packed16),
-                                                       L.ptr(freq), L.ptr(phase), L.ptr(cam2world), L.ptr(u_strat),
-                                                       L.ptr(f_z) if hier else None, L.ptr(g_out), L.ptr(saved_out), L.ptr(a_feat), L.ptr(a_h),
-                                                       L.ptr(a_c), L.ptr(a_g), L.ptr(a_go), L.ptr(scales_t), L.ptr(gmax), C.byref(gvs), _stream()),
-                        "cnerf_field_backward16")
+def free_device_bytes(dev):
+    """What an allocation could get right now: the driver's free memory plus what torch's caching allocator holds unused."""
+    free, _ = torch.cuda.mem_get_info(dev)
+    return free + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
 
-            call((0 if act16 is not None else L.B16_STORE) | L.B16_DRY, step, scales)
-            scales = torch.cat([_pow2_scales(gmax[:nslab]), go_scale])
-            call(L.B16_CHAIN, 1, scales)
-            if DEBUG_CAPTURE is not None:        # scripts/debug_b16.py: the chunk buffers of the first chunk of every pass
-                DEBUG_CAPTURE.setdefault(("b16", pss), dict(feat=a_feat.clone(), h=a_h.clone(), c=a_c.clone(), g=a_g.clone(), go=a_go.clone(),
-                                                            scales=scales.clone(), gmax=gmax.clone(), tpi=tpi, cnt=cnt))
-            fidx = 0
-            for l, kind in enumerate(kinds):
-                X = a_feat if l == 0 else a_h[l - 1]
-                x_ct = n_in if l == 0 else NT
-                dWarg = torch.zeros((cnt, H, 32 * x_ct), dtype=torch.float32, device=dev)   # per image: G^T X
-                cs = torch.zeros((cnt, H), dtype=torch.float32, device=dev)                 # per image: column sums of G
-                L.check(L.lib().cnerf_weight_grad16(cnt, tpi, H, NT, x_ct, L.ptr(a_g[l]), L.ptr(X), L.ptr(dWarg), L.ptr(cs),
-                                                    L.ptr(scales[2 * l + 1:2 * l + 2]), _stream()), "cnerf_weight_grad16")
-                if l == 0:
-                    dWarg = dWarg[..., :k0]                      # drop the zero padding of the last input tile
-                if kind == "film":
-                    sl = slice(fidx * H, (fidx + 1) * H)
-                    f = freq[b0:b0 + cnt, sl]
-                    dW[l] += (f.unsqueeze(-1) * dWarg).sum(0)
-                    db[l] += (f * cs).sum(0)
-                    g_phase[b0:b0 + cnt, sl] += cs
-                    g_freq[b0:b0 + cnt, sl] += (Ws[l].unsqueeze(0) * dWarg).sum(-1) + bs[l].unsqueeze(0) * cs
-                    fidx += 1
-                else:
-                    dW[l] += dWarg.sum(0)
-                    db[l] += cs.sum(0)
-            dWh = torch.zeros((cnt, 4, H), dtype=torch.float32, device=dev)
-            csh = torch.zeros((cnt, 4), dtype=torch.float32, device=dev)
-            L.check(L.lib().cnerf_weight_grad16(cnt, tpi, 4, 1, NT, L.ptr(a_go), L.ptr(a_h[nslab - 1]), L.ptr(dWh), L.ptr(csh),
-                                                L.ptr(scales[2 * nslab + 1:2 * nslab + 2]), _stream()), "cnerf_weight_grad16 (head)")
-            dW_head += dWh.sum(0)
-            db_head += csh.sum(0)
-    grads = []
-    for l in range(nslab):
-        grads += [dW[l], db[l]]
-    grads += [dW_head, db_head]
-    return grad_levels, g_freq, g_phase, grads
+
+def backward_chunk(cfg, bprec_code, B, have_act16, dev):
+    """(images per chunk, workspace bytes) of cnerf_render_backward: the largest chunk whose workspace fits MEMORY_FRACTION of the
+    memory that is free NOW -- not a constant sized for an empty 288 GB part: whatever the encoder, the discriminator
+    and DDP already hold is accounted for, and a smaller or shared device gets smaller chunks instead of an out-of-memory error."""
+    budget = int(MEMORY_FRACTION * free_device_bytes(dev))
+    need = C.c_size_t(0)
+    for nb in ([B] if have_act16 else range(B, 0, -1)):
+        L.check(L.lib().cnerf_backward_workspace_bytes(C.byref(cfg), bprec_code, nb, 1 if have_act16 else 0, C.byref(need)), "cnerf_backward_workspace_bytes")
+        if need.value <= budget or nb == 1:
+            break
+    if need.value > budget:
+        raise L.CnerfError(f"render backward: one image needs {need.value / 2**30:.1f} GiB of chunk buffers, {budget / 2**30:.1f} GiB are free")
+    return nb, need.value
+
+
+MEMORY_FRACTION = 0.8
+LAST_SATURATED = None          # device int32 tensor of the most recent fp16 backward: clamped (tile, matrix) blocks, see include/cnerf.h
 
 
 def render_backward(net, o, levels, freq, phase, cam2world, rng, saved, grad_pixels, grad_depth, act16=None):
-    """Gradients of one render w.r.t. (channel-last feature volumes, freq, phase, [field parameters])."""
-    if backward_precision_of(net) == "fp16":
-        return _render_backward16(net, o, levels, freq, phase, cam2world, rng, saved, grad_pixels, grad_depth, act16)
+    """Gradients of one render w.r.t. (channel-last feature volumes, freq, phase, [field parameters]): ONE call into the library
+    (cnerf_render_backward) for the FiLM / plain-sine / residual families; the per-point FiLM family finishes its mapping-MLP
+    gradients with library GEMMs (_pfilm_backward)."""
+    global LAST_SATURATED
     B, R, S, hier = o["B"], o["R"], o["S"], o["hier"]
     dev = cam2world.device
-    # cfg: precision of the forward (the activation-storing re-run follows it); cfg32: the fp32 gradient chain
+    bprec = backward_precision_of(net)
+    # cfg: precision of the forward (the activation-storing re-run follows it; the fp16 backward re-runs the fp16x3 kernel)
     cfg = make_cfg(net, B, levels, R, S, o["fov"], o["ray_start"], o["ray_end"], o["noise_std"], hier,
-                   o["white_back"], o["last_back"], o["clamp_mode"], philox=rng.get("philox"), drop=drop_of(rng))
-    cfg32 = make_cfg(net, B, levels, R, S, o["fov"], o["ray_start"], o["ray_end"], o["noise_std"], hier,
-                     o["white_back"], o["last_back"], o["clamp_mode"], precision="fp32", philox=rng.get("philox"), drop=drop_of(rng))
+                   o["white_back"], o["last_back"], o["clamp_mode"], precision="fp16x3" if bprec == "fp16" else None,
+                   philox=rng.get("philox"), drop=drop_of(rng))
+    c_rs, c_z, f_rs, f_z = saved[:4]
+    grad_pixels = _f32(grad_pixels)
+    grad_depth = _f32(grad_depth) if grad_depth is not None else None
     if net.spec.layers[0] == "pfilm":
-        c_rs, c_z, f_rs, f_z = saved[:4]
         gc = torch.empty_like(c_rs)
         gf = torch.empty_like(f_rs) if hier else None
         eps_final = _f32(rng.get("eps_final")) if o["noise_std"] != 0 else None
-        gd = _f32(grad_depth) if grad_depth is not None else None
         L.check(L.lib().cnerf_merge_composite_backward(C.byref(cfg), L.ptr(c_rs), L.ptr(c_z), L.ptr(f_rs) if hier else None,
-                                                       L.ptr(f_z) if hier else None, L.ptr(eps_final), L.ptr(_f32(grad_pixels)),
-                                                       L.ptr(gd), L.ptr(gc), L.ptr(gf) if hier else None, _stream()),
+                                                       L.ptr(f_z) if hier else None, L.ptr(eps_final), L.ptr(grad_pixels),
+                                                       L.ptr(grad_depth), L.ptr(gc), L.ptr(gf) if hier else None, _stream()),
                 "cnerf_merge_composite_backward")
         return _pfilm_backward(net, o, cfg, levels, cam2world, rng, saved, gc, gf)
-    vs = volumes_struct(levels)
     packed = pack_field(net, cfg)
-    packed_t = pack_field_transposed(net, cfg32)
-    H, k0 = int(net.hidden_dim), int(net.input_dim)
-    n_in = cfg.C // 32 + (1 if net.spec.input == "feat_xyz" else 0)
-    kinds = net.spec.layers
-    nl = len(kinds)
-    npi = R * R * S
-    c_rs, c_z, f_rs, f_z = saved[:4]
-    gc = torch.empty_like(c_rs)
-    gf = torch.empty_like(f_rs) if hier else None
-    grad_pixels = _f32(grad_pixels)
-    grad_depth = _f32(grad_depth) if grad_depth is not None else None
-    eps_final = _f32(rng.get("eps_final")) if o["noise_std"] != 0 else None
-    L.check(L.lib().cnerf_merge_composite_backward(C.byref(cfg), L.ptr(c_rs), L.ptr(c_z), L.ptr(f_rs) if hier else None,
-                                                   L.ptr(f_z) if hier else None, L.ptr(eps_final), L.ptr(grad_pixels),
-                                                   L.ptr(grad_depth), L.ptr(gc), L.ptr(gf) if hier else None, _stream()),
-            "cnerf_merge_composite_backward")
-
-    params = net.field_params()
-    Ws, bs, slab_of = [], [], []      # one entry per matrix ("slab"): a residual block contributes fc1 and fc2
-    it = iter(params)
-    for kind in kinds:
-        for _ in range(2 if kind == "res" else 1):
-            Ws.append(next(it).detach()); bs.append(next(it).detach())
-            slab_of.append("sine" if kind == "res" else kind)
-    nslab = len(Ws)
-    W_head = next(it).detach()
-    dW = [torch.zeros_like(w) for w in Ws]
-    db = [torch.zeros_like(b) for b in bs]
-    dW_head = torch.zeros_like(W_head)
-    db_head = torch.zeros(4, dtype=torch.float32, device=dev)
-    n_film = sum(1 for k in kinds if k == "film")
+    if bprec == "fp16":
+        packed_bwd = pack_field_chain16(net, cfg)
+    else:
+        cfg32 = make_cfg(net, B, levels, R, S, precision="fp32")
+        packed_bwd = pack_field_transposed(net, cfg32)
+    params = [_f32(p.detach()) for p in net.field_params()]
+    grads = [torch.zeros_like(p) for p in params]
+    fp, gp = _field_params_struct(net, params), _field_param_grads_struct(net, grads)
+    n_film = sum(1 for k in net.spec.layers if k == "film")
+    H = int(net.hidden_dim)
     g_freq = torch.zeros((B, n_film * H), dtype=torch.float32, device=dev) if n_film else None
     g_phase = torch.zeros_like(g_freq) if n_film else None
     grad_levels = [torch.zeros_like(v) for v in levels]
-    gvs = volumes_struct(grad_levels)
-
-    per_image = npi * (32 * n_in + 3 * nslab * H + 4) * 4
-    nb = max(1, min(B, ACT_BUDGET_BYTES // per_image))
-    act = None
-    u_strat, fine_z_used = _f32(rng.get("u_strat")), f_z
-    passes = [(0, gc, c_rs)] + ([(1, gf, f_rs)] if hier else [])
-    for pss, g_out, saved_out in passes:
-        for b0 in range(0, B, nb):
-            cnt = min(nb, B - b0)
-            n = cnt * npi
-            if act is None or act[0].shape[0] != n:
-                act = (torch.empty((n, 32 * n_in), dtype=torch.float32, device=dev),
-                       torch.empty((nslab, n, H), dtype=torch.float32, device=dev),
-                       torch.empty((nslab, n, H), dtype=torch.float32, device=dev),
-                       torch.empty((nslab, n, H), dtype=torch.float32, device=dev),
-                       torch.empty((n, 4), dtype=torch.float32, device=dev))
-            a_feat, a_h, a_c, a_g, a_go = act
-            L.check(L.lib().cnerf_field_backward(C.byref(cfg), pss, b0, cnt, C.byref(vs), L.ptr(packed), L.ptr(packed_t),
-                                                 L.ptr(freq), L.ptr(phase), L.ptr(cam2world), L.ptr(u_strat),
-                                                 L.ptr(fine_z_used) if hier else None, L.ptr(g_out), L.ptr(saved_out),
-                                                 L.ptr(a_feat), L.ptr(a_h), L.ptr(a_c), L.ptr(a_g), L.ptr(a_go),
-                                                 C.byref(gvs), L.ptr(_u8(rng.get("drop_fine" if pss else "drop_coarse"))), _stream()),
-                    "cnerf_field_backward")
-            if DEBUG_CAPTURE is not None:
-                DEBUG_CAPTURE.setdefault(("f32", pss), dict(feat=a_feat.clone(), h=a_h.clone(), c=a_c.clone(), g=a_g.clone(), go=a_go.clone(), cnt=cnt))
-            # parameter gradients: plain GEMMs and column sums over the chunk matrices (rocBLAS through torch)
-            fidx = 0
-            for l, kind in enumerate(slab_of):
-                X = a_feat if l == 0 else a_h[l - 1]
-                K = X.shape[-1]
-                dWarg = torch.zeros((cnt, H, K), dtype=torch.float32, device=dev)    # per image: G^T X
-                cs = torch.zeros((cnt, H), dtype=torch.float32, device=dev)          # per image: column sums of G
-                L.check(L.lib().cnerf_weight_grad(cnt, npi, H, K, L.ptr(a_g[l]), L.ptr(X), L.ptr(dWarg), L.ptr(cs), _stream()),
-                        "cnerf_weight_grad")
-                if l == 0:
-                    dWarg = dWarg[..., :k0]                      # drop the zero padding of the last input tile
-                if kind == "film":
-                    sl = slice(fidx * H, (fidx + 1) * H)
-                    f = freq[b0:b0 + cnt, sl]
-                    dW[l] += (f.unsqueeze(-1) * dWarg).sum(0)
-                    db[l] += (f * cs).sum(0)
-                    g_phase[b0:b0 + cnt, sl] += cs
-                    g_freq[b0:b0 + cnt, sl] += (Ws[l].unsqueeze(0) * dWarg).sum(-1) + bs[l].unsqueeze(0) * cs
-                    fidx += 1
-                else:
-                    dW[l] += dWarg.sum(0)
-                    db[l] += cs.sum(0)
-            dW_head += a_go.t() @ a_h[nslab - 1]
-            db_head += a_go.sum(0)
-    grads = []
-    for l in range(nslab):
-        grads += [dW[l], db[l]]
-    grads += [dW_head, db_head]
+    vs, gvs = volumes_struct(levels), volumes_struct(grad_levels)
+    code = L.PREC_CODE[bprec]
+    nb, ws_bytes = backward_chunk(cfg, code, B, act16 is not None, dev)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    sat = torch.zeros(1, dtype=torch.int32, device=dev)
+    keep = [_f32(rng.get(k)) for k in ("u_strat", "eps_final")] + [_u8(rng.get(k)) for k in ("drop_coarse", "drop_fine")]
+    r = L.Rng()
+    r.u_strat, r.eps_final, r.drop_coarse, r.drop_fine = [None if t is None else t.data_ptr() for t in keep]
+    for t in keep:
+        L.ptr(t)
+    sv = L.Saved()
+    sv.coarse_rgb_sigma, sv.coarse_z = c_rs.data_ptr(), c_z.data_ptr()
+    if hier:
+        sv.fine_rgb_sigma, sv.fine_z = f_rs.data_ptr(), f_z.data_ptr()
+    for t in (c_rs, c_z) + ((f_rs, f_z) if hier else ()):
+        L.ptr(t)
+    aux = None
+    if act16 is not None:
+        aux = L.Aux()
+        for i, bufs in enumerate(act16):
+            aux.act16[i].feat, aux.act16[i].h, aux.act16[i].c = (t.data_ptr() for t in bufs)
+    L.check(L.lib().cnerf_render_backward(C.byref(cfg), code, nb, C.byref(vs), C.byref(fp), L.ptr(packed), L.ptr(packed_bwd), L.ptr(freq), L.ptr(phase),
+                                          L.ptr(cam2world), C.byref(r), C.byref(sv), C.byref(aux) if aux is not None else None,
+                                          L.ptr(grad_pixels), L.ptr(grad_depth), C.byref(gp), L.ptr(g_freq), L.ptr(g_phase), C.byref(gvs),
+                                          L.ptr(sat) if bprec == "fp16" else None, L.ptr(ws), _stream()), "cnerf_render_backward")
+    if bprec == "fp16":
+        LAST_SATURATED = sat
     return grad_levels, g_freq, g_phase, grads
 
 

@@ -265,6 +265,13 @@ class GanTrainer:
         self.losses["g"].append(g_acc / len(chunks))
         self.losses["photo"].append(p_acc / len(chunks))
         self.last.update(g_loss=g_acc / len(chunks), photo_loss=p_acc / len(chunks))
+        # half-precision render backward: (tile, matrix) blocks whose stored gradients left fp16's range and were clamped -- the
+        # per-matrix scale comes from a sampled maximum (include/cnerf.h, cnerf_render_backward).  Non-zero: outlier gradients were
+        # cut; train with backward_precision "fp32" if that matters.
+        from .. import ops
+        if getattr(ops, "LAST_SATURATED", None) is not None:
+            self.last["render_bwd_clamped_blocks"] = int(ops.LAST_SATURATED.item())
+            ops.LAST_SATURATED = None
 
     def warm_convolutions(self, sample):
         """One throw-away forward + backward of the encoder and the discriminator on the RAW modules (no DDP collective, no

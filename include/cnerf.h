@@ -350,6 +350,56 @@ int cnerf_field_backward16(const cnerf_cfg* cfg, uint32_t mode, int32_t group_st
                            void* act_g16, void* act_go16, const float* scales, uint32_t* gmax, const cnerf_grad_volumes* grad_vols,
                            void* stream);
 
+/* ---- the whole backward in ONE call (ABI v6) --------------------------------------------------------------------------
+ * Autograd twin of cnerf_render_forward for hosts without an autograd engine of their own (and the path the PyTorch mirror
+ * takes): given d loss / d pixels and d loss / d depth it runs the steps above -- cnerf_merge_composite_backward, then per
+ * pass (coarse, fine) and per chunk of images the activation-storing re-run of the forward (unless the forward kept its
+ * activations: aux->act16), the gradient chain, the volume scatter, one weight reduction per matrix -- and finishes what the
+ * round-2 ABI left to the host: dW_l = diag(freq_l) dWarg_l, db_l, dfreq_l, dphase_l per image, the head's dW / db.
+ * Replaces loss.backward() through ImplicitGenerator3d.forward (utils.py:638-711; generators.py:33-187 under autograd).
+ *
+ *   backward_precision  CNERF_PREC_FP32: exact fp32 chain and weight reductions (re-run in cfg->precision);
+ *                       CNERF_PREC_FP16: fp16 operands, fp32 sums (cnerf_field_backward16 / cnerf_weight_grad16; cfg->precision must
+ *                       be CNERF_PREC_FP16X3).  Per-point FiLM networks: CNERF_ENOSYS (their mapping-MLP reductions are library GEMMs on
+ *                       the host: cnerf_field_backward + cnerf_weight_grad + cnerf_scatter_features).
+ *   params              the raw parameters (dfreq needs W_l and b_l);  packed: cnerf_pack_field in cfg->precision;
+ *   packed_bwd          cnerf_pack_field_transposed (fp32 backward) or cnerf_pack_field_chain16 (fp16 backward).
+ *   saved               the forward's coarse / fine rgb_sigma and z (cnerf_aux of that call; fine_* NULL when not hierarchical).
+ *   rng                 the forward's cnerf_rng -- u_strat, eps_final, dropout masks; Philox draws follow cfg as in the forward.
+ *   act16               the activations the forward kept (cnerf_aux.act16, fp16 backward only) or NULL: re-computed per chunk.
+ *   grads               per parameter a buffer of the parameter's shape, ACCUMULATED INTO (zero them first); NULL entries are
+ *                       skipped.  grad_freq / grad_phase (B, n_film * H), grad_vols (shapes of vols): accumulated into as well.
+ *   images_per_chunk    images whose activation / gradient buffers live in the workspace at a time (1..B; with act16 given
+ *                       all B).  workspace: cnerf_backward_workspace_bytes(cfg, backward_precision, images_per_chunk, act16 != NULL).
+ *   saturated           optional DEVICE uint32 (zero it first), fp16 backward: incremented once per (tile, matrix) in which a stored
+ *                       gradient exceeded fp16's range and was clamped -- the per-matrix scale comes from a SAMPLED maximum
+ *                       (every 16th tile group once there are >= 32768 of them); non-zero means: repeat with exhaustive sampling
+ *                       (cnerf_field_backward16 with group_step 1) or in fp32. */
+typedef struct cnerf_field_param_grads {
+    float* w[CNERF_MAX_LAYERS];
+    float* b[CNERF_MAX_LAYERS];
+    float* w2[CNERF_MAX_LAYERS];
+    float* b2[CNERF_MAX_LAYERS];
+    float* w_final;
+    float* b_final;
+} cnerf_field_param_grads;
+
+typedef struct cnerf_saved {
+    const float* coarse_rgb_sigma; /* (B,P,S,4) */
+    const float* coarse_z;         /* (B,P,S)   */
+    const float* fine_rgb_sigma;   /* (B,P,S,4) or NULL */
+    const float* fine_z;           /* (B,P,S) or NULL: the depths the fine pass used */
+} cnerf_saved;
+
+int cnerf_backward_workspace_bytes(const cnerf_cfg* cfg, int32_t backward_precision, int32_t images_per_chunk, int32_t have_act16,
+                                   size_t* bytes);
+int cnerf_render_backward(const cnerf_cfg* cfg, int32_t backward_precision, int32_t images_per_chunk, const cnerf_volumes* vols,
+                          const cnerf_field_params* params, const float* packed, const void* packed_bwd, const float* freq,
+                          const float* phase, const float* cam2world, const cnerf_rng* rng, const cnerf_saved* saved,
+                          const cnerf_aux* act16, const float* grad_pixels, const float* grad_depth,
+                          const cnerf_field_param_grads* grads, float* grad_freq, float* grad_phase,
+                          const cnerf_grad_volumes* grad_vols, uint32_t* saturated, void* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,9 +1,6 @@
-"""A/B of the unfused lookup kernel's visiting order (CNERF_GATHER_TILING, csrc/ray_kernels.hip): ms per 16.8 M lookups of the
-bench step (8 images, 128x128 rays, 64 coarse + 64 fine samples).  One process per mode (the switch is read once).
-    python scripts/ab_gather.py            # parent: runs every mode
-"""
+"""A/B of the two forms of the unfused lookup (csrc/ray_kernels.hip): ms per 16.8 M lookups of the bench step (8 images, 128x128
+rays, 64 coarse + 64 fine samples), and that they agree bit for bit.    python scripts/ab_gather.py"""
 import os
-import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -29,24 +26,22 @@ def child():
         fcl = ops.channel_last(fvol)
         pts = [aux[k].reshape(B, -1, 3).contiguous() for k in ("coarse_points", "fine_points")]
         del aux
-        ref = [ops.gather_features(gen.siren, fcl, p) for p in pts]          # no hint: linear order
-        out = [ops.gather_features(gen.siren, fcl, p, R, S) for p in pts]
+        ref = [ops.gather_features(gen.siren, fcl, p) for p in pts]          # no hint: point by point in ray order (gather_kernel)
+        out = [ops.gather_features(gen.siren, fcl, p, R, S) for p in pts]    # hint: patches, distinct lines once (gather_box_kernel)
         same = all(torch.equal(a, b) for a, b in zip(ref, out))
         del ref, out
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-        for i in range(12):
-            if i == 2:
-                ev[0].record()
-            for p in pts:
-                ops.gather_features(gen.siren, fcl, p, R, S)
-        ev[1].record()
-        torch.cuda.synchronize()
-    print(f"CNERF_GATHER_TILING={os.environ.get('CNERF_GATHER_TILING')}: {ev[0].elapsed_time(ev[1]) / 10:.3f} ms per 16.8 M lookups, bit-identical to linear order: {same}", flush=True)
+        for name, hint in (("gather_kernel (no hint)", ()), ("gather_box_kernel (R, S hint)", (R, S))):
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            for i in range(12):
+                if i == 2:
+                    ev[0].record()
+                for p in pts:
+                    ops.gather_features(gen.siren, fcl, p, *hint)
+            ev[1].record()
+            torch.cuda.synchronize()
+            print(f"{name}: {ev[0].elapsed_time(ev[1]) / 10:.3f} ms per 16.8 M lookups", flush=True)
+    print("bit-identical:", same, flush=True)
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "child":
-        child()
-    else:
-        for mode in sys.argv[1:] or ["0", "1", "2", "3", "4", "5"]:
-            subprocess.run([sys.executable, os.path.abspath(__file__), "child"], env=dict(os.environ, CNERF_GATHER_TILING=mode), check=True)
+    child()

@@ -18,11 +18,13 @@ os.makedirs(os.environ["MIOPEN_USER_DB_PATH"], exist_ok=True)
 import numpy as np
 import torch
 import cnerf_amd
+from cnerf_amd.training.miopen_db import use_shipped_db
+use_shipped_db(os.environ["MIOPEN_USER_DB_PATH"])        # start from what is already known: only new shapes are searched
 from cnerf_amd.training import GanTrainer, default_metadata
 from cnerf_amd.training.gan_step import synthetic_sample
 
 dev = torch.device("cuda:0")
-for disc in ("CCSDiscriminator", "ProgressiveDiscriminator"):
+for disc in os.environ.get("CNERF_DB_DISCRIMINATORS", "CCSDiscriminator,ProgressiveDiscriminator").split(","):
     for batch in [int(a) for a in sys.argv[1:]] or [8, 2]:
         torch.manual_seed(0)
         np.random.seed(0)

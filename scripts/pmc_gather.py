@@ -26,7 +26,7 @@ for mode in (0, 1):
                     times.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6)
     out[mode] = ({c: sum(v) / len(v) for c, v in vals.items()}, sum(times) / max(len(times), 1))
 names = sorted(set(out[0][0]) | set(out[1][0]))
-print("| counter (sum over instances, per launch of 2,097,152 lookups) | linear order | patch order 4x4x2 |")
+print("| counter (sum over instances, per launch of 2,097,152 lookups) | gather_kernel (point by point, ray order) | gather_box_kernel (4x4x2 patches, distinct lines once via LDS) |")
 print("|---|---|---|")
 print(f"| kernel ms (under PMC, mean over all passes) | {out[0][1]:.4f} | {out[1][1]:.4f} |")
 for n in names:

@@ -1,5 +1,5 @@
-# rocprofv3 PMC counters of the unfused lookup kernel (cnerf_gather_features) in its two visiting orders -- CNERF_GATHER_TILING=0
-# linear (32 consecutive samples of a ray per block iteration), 1 patch (4x4 pixels x 2 depths) -- to see what bounds it: texture
+# rocprofv3 PMC counters of the unfused lookup (cnerf_gather_features) in its two forms -- CNERF_GATHER_HINT=0: gather_kernel, point by
+# point in ray order; 1: gather_box_kernel, 4x4x2 patches with every distinct corner line fetched once into LDS -- to see what bounds it: texture
 mkdir -p gpurun_out/r3
 # addresser, vector L1 (hits, pending-miss stalls), L2.  One pass per counter set, batch 2 at 128x128x(64+64).
 # scripts/pmc_gather.py renders gpurun_out/r3/pmc_gather.md
@@ -16,7 +16,7 @@ for C in "GRBM_GUI_ACTIVE TA_TA_BUSY TA_ADDR_STALLED_BY_TC_CYCLES TA_DATA_STALLE
          "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
   for M in 0 1; do
-    CNERF_GATHER_TILING=$M timeout -k 10 200 rocprofv3 --kernel-trace --pmc $C -d gpurun_out/r3/pmcg_${M}_$i -o x --output-format csv -- python3 scripts/profile_workload.py 2 3 > gpurun_out/r3/pmcg_${M}_$i.log 2>&1 || echo "set $i mode $M failed"
+    CNERF_GATHER_HINT=$M timeout -k 10 200 rocprofv3 --kernel-trace --pmc $C -d gpurun_out/r3/pmcg_${M}_$i -o x --output-format csv -- python3 scripts/profile_workload.py 2 3 > gpurun_out/r3/pmcg_${M}_$i.log 2>&1 || echo "set $i mode $M failed"
   done
 done
 python3 scripts/pmc_gather.py > gpurun_out/r3/pmc_gather.md

@@ -200,6 +200,14 @@ def test_lookup_patch_order_is_bit_identical(dev, shape):
     ref = torch.nn.functional.grid_sample(cl.permute(0, 4, 1, 2, 3), (pts / 0.6).reshape(B, 1, 1, -1, 3), mode="bilinear", align_corners=False,
                                           padding_mode="border").reshape(B, 32, -1).permute(0, 2, 1)
     assert (b - ref).abs().max().item() < 1e-4      # (torch's GPU kernel contracts to fma: not bit-identical, the CPU one is -- goldens)
+    # ray-like points (neighbouring pixels a fraction of a voxel apart, as in a render): the tiles are reducible -- distinct corner lines
+    # fetched once into LDS -- where the random points above take the kernel's point-by-point fallback
+    if R % 4 == 0 and S % 2 == 0:
+        rr, cc, ss = torch.meshgrid(torch.arange(R, device=dev), torch.arange(R, device=dev), torch.arange(S, device=dev), indexing="ij")
+        zz = (ss + torch.rand(R, R, S, device=dev)) / S
+        ray = torch.stack([(cc / R - 0.5) * 0.9 * (0.4 + zz), (rr / R - 0.5) * 0.9 * (0.4 + zz), zz * 1.3 - 0.65], -1).reshape(1, R * R * S, 3)
+        pts = (ray + 0.02 * torch.randn(B, 1, 3, device=dev)).contiguous()
+        assert torch.equal(cnerf_amd.ops.gather_features(gen.siren, cl, pts), cnerf_amd.ops.gather_features(gen.siren, cl, pts, R, S))
 
 
 @pytest.mark.parametrize("name", GOLDEN_NAMES)

@@ -145,3 +145,33 @@ def test_philox_dropout_keep_layout():
     assert keep[d, pt, c] == int(int(words[c % 4]) >= int(p * 2 ** 32 + 0.5))
     assert not np.array_equal(keep, P.dropout_keep(seed, off, 5, n_pts, n_drop, H, p))      # the fine pass draws from its own stream
     assert P.dropout_keep(seed, off, 4, n_pts, n_drop, H, 0.0).all()
+
+
+def test_backward_workspace_validation_without_gpu():
+    """cnerf_backward_workspace_bytes (host code of the one-call backward): sizes grow with the chunk, kept activations shrink them,
+    and what the call cannot do is refused with a message -- per-point FiLM (CNERF_ENOSYS), an fp16 backward behind an fp32 forward cfg."""
+    import cnerf_amd
+    L = cnerf_amd._lib
+    cfg = L.Cfg()
+    cfg.B, cfg.R, cfg.S, cfg.V, cfg.C, cfg.H, cfg.L = 4, 16, 8, 8, 32, 64, 4
+    cfg.voxel_length, cfg.fov_deg, cfg.flags = 1.2, 30.0, L.F_HIERARCHICAL
+    n = ctypes.c_size_t()
+    sizes = {}
+    for prec in (L.PREC_FP32, L.PREC_FP16):
+        cfg.precision = L.PREC_FP32 if prec == L.PREC_FP32 else L.PREC_FP16X3
+        for cnt in (1, 4):
+            assert L.lib().cnerf_backward_workspace_bytes(ctypes.byref(cfg), prec, cnt, 0, ctypes.byref(n)) == 0, L.lib().cnerf_last_error()
+            sizes[(prec, cnt)] = n.value
+    npi = 16 * 16 * 8
+    assert sizes[(L.PREC_FP32, 4)] > sizes[(L.PREC_FP32, 1)] >= 2 * 4 * npi * 16 + npi * (32 + 3 * 4 * 64 + 4) * 4
+    assert sizes[(L.PREC_FP16, 4)] < sizes[(L.PREC_FP32, 4)]                      # fp16 tile blocks are half the bytes
+    assert L.lib().cnerf_backward_workspace_bytes(ctypes.byref(cfg), L.PREC_FP16, 4, 1, ctypes.byref(n)) == 0
+    assert n.value < sizes[(L.PREC_FP16, 4)]                                       # kept activations are not part of the workspace
+    assert L.lib().cnerf_backward_workspace_bytes(ctypes.byref(cfg), L.PREC_FP16, 2, 1, ctypes.byref(n)) == -22      # kept: all images at once
+    assert L.lib().cnerf_backward_workspace_bytes(ctypes.byref(cfg), L.PREC_FP16, 5, 0, ctypes.byref(n)) == -22
+    cfg.precision = L.PREC_FP32
+    assert L.lib().cnerf_backward_workspace_bytes(ctypes.byref(cfg), L.PREC_FP16, 1, 0, ctypes.byref(n)) == -22
+    assert b"fp16x3" in L.lib().cnerf_last_error()
+    for l in range(4):
+        cfg.layer_kind[l] = L.LAYER_PFILM
+    assert L.lib().cnerf_backward_workspace_bytes(ctypes.byref(cfg), L.PREC_FP32, 1, 0, ctypes.byref(n)) == -38

@@ -36,7 +36,8 @@ def main():
                     help="arithmetic of the forward render: fp16x3 = fp32-accurate split products (same 1e-4 parity gate as fp32, 2.5x faster)")
     ap.add_argument("--backward-precision", default="fp16", choices=["fp32", "fp16"],
                     help="gradient GEMMs of the render backward: fp16 operands with fp32 sums (gradients within 1e-3 relative L2 of fp32 "
-                         "autograd; the reference itself trains under fp16 autocast), or the exact fp32 MFMA chain (3.5x slower)")
+                         "autograd; the reference itself trains under fp16 autocast), or the exact fp32 MFMA chain (3.5x slower).  NOTE: the "
+                         "defaults of this script (fp16x3 forward, fp16 backward) are the fast training arithmetic, not the fp32 parity path")
     ap.add_argument("--encoder-autocast", default=None, choices=["bf16", "fp16"],
                     help="run the 3D U-Net's convolutions under torch.autocast (the reference trains under fp16 autocast)")
     ap.add_argument("--teacher", action="store_true",
@@ -121,7 +122,9 @@ def main():
     if md["miopen_find"]:
         # MIOpen's kernel search runs once per node: rank 0 first, the others after it (they find its results in the shared user
         # database instead of searching for ~7 minutes each, all at once)
-        os.environ.setdefault("MIOPEN_USER_DB_PATH", os.path.join(os.path.expanduser("~"), ".config", "miopen"))
+        # ... and starts from the find results shipped with the repo for the default sizes (training/miopen_db.py): nothing to search then
+        from cnerf_amd.training.miopen_db import use_shipped_db
+        use_shipped_db()
         warm = synthetic_sample(args.batch, args.img_size, args.voxel_res, dev, torch.Generator().manual_seed(1))
         def search():
             t0 = time.perf_counter()
@@ -152,6 +155,9 @@ def main():
             print(f"step {step}: D {d_loss:.4f}  G {trainer.losses['g'][-1]:.4f}  photo {trainer.losses['photo'][-1]:.4f}  "
                   f"alpha {trainer.alpha:.3f}  nerf_noise {md['nerf_noise']:.3f}  sec/step {dt:.3f}  "
                   f"({world * args.batch * args.img_size ** 2 * 2 / dt / 1e6:.2f} M rays/s rendered, D + G passes)", flush=True)
+            if trainer.last.get("render_bwd_clamped_blocks"):
+                print(f"  warning: the fp16 render backward clamped gradients in {trainer.last['render_bwd_clamped_blocks']} (tile, matrix) blocks "
+                      f"(outliers beyond 32x the sampled maximum); --backward-precision fp32 is exact", flush=True)
     if args.checkpoint_dir and rank == 0:
         from cnerf_amd.training import save_checkpoint
         trainer.generator.step -= 1                       # the step that was just completed, as the reference names its files
