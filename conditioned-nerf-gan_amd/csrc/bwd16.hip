@@ -341,15 +341,18 @@ __global__ __launch_bounds__(256) void chain16_kernel(Chain16Args A) {
     };
     // every wave, at the start of every unit: this wave's share of the unit's copy (requested two units ago) must have landed.
     // vmcnt retires in order.  `steady` (second and later units of a matrix): since that request the wave has issued, in
-    // order, the cos loads (4 per output tile) and g16 stores (up to 4 per tile) of two units and the NEXT unit's PW copy
-    // pieces -- at least 16 + PW operations whatever the mode (an idle wave and the dry run issue no stores), so waiting
-    // until at most 16 + PW are outstanding guarantees the copy and leaves the most recent stores / loads in flight under the
-    // MFMAs (a full drain here cost ~0.5 us per unit).  Elsewhere the operation count is irregular: full drain.
-    constexpr int STEADY_N = 16 + PW;
+    // order, the cos loads of the tiles in between (4 per prefetch; unit 0 of a matrix prefetches once, every other unit twice, the
+    // tail of a matrix once more) and the NEXT unit's PW copy pieces, plus -- unless it is idle or this is the dry run -- 4 gradient
+    // stores per tile: at least 12 + PW operations in every case (u = 2 at H = 256: 4 + 8 loads + PW; u = 1, 3: 16 + PW), so waiting
+    // until at most 12 + PW are outstanding guarantees the copy and leaves the most recent stores / loads in flight under the MFMAs.
+    // Elsewhere the operation count is irregular: full drain.  The barrier itself orders LDS only (lds_only_barrier, cnerf_dev.hpp):
+    // __syncthreads() would drain every gradient store in flight at every unit (round 2 did, unknowingly: its counted wait sat in
+    // front of a release fence that the compiler turned into vmcnt(0) -- and its count, 16 + PW, was 4 too many for u = 2).
+    constexpr int STEADY_N = 12 + PW;
     auto unit_begin = [&](bool steady) -> const f16x8* {
-        if (steady) __builtin_amdgcn_s_waitcnt(0x0F70 | (STEADY_N & 15) | ((STEADY_N >> 4) << 14));
-        else __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0)
-        __syncthreads();                                        // everybody's share has landed; nobody still reads the slot refilled next
+        if (steady) wait_vmcnt<STEADY_N>();
+        else wait_vmcnt<0>();
+        lds_only_barrier();                                     // everybody's share has landed; nobody still reads the slot refilled next
         dma_next();
         const f16x8* u = lds_units + use_slot * UNIT_FR;
         use_slot = use_slot == 2 ? 0 : use_slot + 1;

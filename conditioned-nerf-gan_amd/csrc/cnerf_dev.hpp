@@ -293,4 +293,24 @@ __device__ __forceinline__ void trilinear_corners(float px, float py, float pz, 
     }
 }
 
+// Workgroup barrier that drains nothing.  __syncthreads() carries a release fence, which the compiler implements as
+// s_waitcnt vmcnt(0): every global store, float atomic and load the wave has in flight is drained at the barrier (an LDS-only
+// fence -- __builtin_amdgcn_fence(..., "workgroup", "local") -- does the same as soon as an LDS-DMA copy is pending, because those
+// are counted by vmcnt too; measured on the ISA).  In kernels that stream weight units through LDS behind one barrier per unit
+// AND write activations or gradients to HBM (the activation-storing forward, the gradient chain) that exposed an HBM round trip
+// at every unit.  Here: the bare s_barrier between two compiler-level memory barriers (no memory access is moved across it), and
+// the caller states what it needs to have completed: wait_vmcnt<N>() with N = the number of vector-memory operations it has issued
+// SINCE the LDS-DMA copy it is about to read (vmcnt retires in issue order; those N may stay in flight), and nothing for its LDS
+// reads of the slot that is refilled next -- their data has already been consumed by issued MFMAs.
+__device__ __forceinline__ void lds_only_barrier() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {      // at most N vector-memory operations outstanding (gfx9 encoding: 6 bits, split)
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+    __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14));
+}
+
 }  // namespace cnerf

@@ -432,6 +432,8 @@ __device__ __forceinline__ void h3_layer0_from_lds(const f16x8* lds_unit, const 
 #define BSTAMP(i)
 #endif
 
+template <int N>
+struct Younger { static constexpr int value = N; };            // compile-time tag of unit_begin() in the kernel
 struct ResidNo { static constexpr bool value = false; };      // compile-time tags for the `matrix` lambda of the kernel
 struct ResidYes { static constexpr bool value = true; };
 
@@ -503,9 +505,23 @@ __global__ __launch_bounds__(256) void field_h3_kernel(FieldArgs a) {
         dma_k = dma_k + 1 == n_units ? 0 : dma_k + 1;
         dma_slot = (dma_slot + 1) & (SLOTS - 1);
     };
-    // every wave, at the start of every unit
-    auto unit_begin = [&]() -> const f16x8* {
-        __syncthreads();
+    // every wave, at the start of every unit.  Plain forward: __syncthreads() (its vmcnt(0) also lands the wave's share of the copy).
+    // Activation-storing forward: the barrier must NOT drain the activation stores in flight (an HBM write round trip at every unit:
+    // this alone made the storing forward 16.4 ms against 10.7 plain) -- lds_only_barrier() behind a counted wait.  YOUNGER = a lower
+    // bound, known at every call site, on the vector-memory operations this wave has issued since it requested the copy of the unit
+    // it is about to read (the request of the previous unit_begin): the activation stores of the epilogues in between, 8 per output
+    // tile (4 quads x {sin, cos}); a wave without a tile of its own (`store_live` false) stores nothing and waits for everything.
+    bool store_live = true;
+    auto unit_begin = [&](auto younger_tag) -> const f16x8* {
+        constexpr int YOUNGER = decltype(younger_tag)::value;
+        if constexpr (STORE == STORE_NONE) {
+            __syncthreads();
+        } else {
+            if (YOUNGER >= 16 && store_live) wait_vmcnt<16>();
+            else if (YOUNGER >= 8 && store_live) wait_vmcnt<8>();
+            else wait_vmcnt<0>();
+            lds_only_barrier();
+        }
         dma_next();
         const f16x8* unit = lds + use_slot * UNIT_FR;
         use_slot = (use_slot + 1) & (SLOTS - 1);
@@ -575,6 +591,7 @@ __global__ __launch_bounds__(256) void field_h3_kernel(FieldArgs a) {
         const long long tile_T = (long long)b * a.tiles_per_image + tile_in_image;
         const size_t slab16 = (size_t)a.total_tiles * NT * 1024;      // fp16 elements per slab (a.total_tiles = tiles of the chunk)
         st.live = tile_in_image < a.tiles_per_image;
+        store_live = STORE == STORE_F32 || st.live;                   // (fp32 rows: idle waves re-store the image's last point)
         st.blk_h = STORE == STORE_TB16 ? reinterpret_cast<_Float16*>(a.act_h) + ((size_t)tile_T * NT * 32 + j) * 32 : nullptr;
         st.blk_c = STORE == STORE_TB16 ? reinterpret_cast<_Float16*>(a.act_c) + ((size_t)tile_T * NT * 256 + lane) * 4 : nullptr;
         // ---- layer 0: one weight unit per input tile ------------------------------------------------------------------
@@ -586,7 +603,7 @@ __global__ __launch_bounds__(256) void field_h3_kernel(FieldArgs a) {
                 for (int r = 0; r < 16; ++r) acc0[t][r] = 0.0f;
             for (int tk = 0; tk < a.n_in; ++tk) {
                 if (tk > 0) input_tile_issue(a, b, tk, px, py, pz, h, it);   // tile 0 was issued during the previous head
-                const f16x8* unit = unit_begin();
+                const f16x8* unit = unit_begin(Younger<0>{});      // (behind the head: the next tile's lookups are in flight and needed now)
                 const f32x16 feat = input_tile_reduce(it, px, py, pz, h);
                 float fv[16];
 #pragma unroll
@@ -649,7 +666,9 @@ __global__ __launch_bounds__(256) void field_h3_kernel(FieldArgs a) {
             FilmPair fp;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                const f16x8* unit = unit_begin();
+                // since the previous unit's request: t = 0: the epilogues of the last two tiles of the matrix before (first hidden matrix:
+                // layer 0's, NT >= 2 tiles) = 16 stores; t = 1: nothing (tile 0 has no epilogue to run under it); t >= 2: tile t-2's 8
+                const f16x8* unit = t == 0 ? unit_begin(Younger<16>{}) : t == 1 ? unit_begin(Younger<0>{}) : unit_begin(Younger<8>{});
                 f32x16 acc;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
@@ -699,7 +718,7 @@ __global__ __launch_bounds__(256) void field_h3_kernel(FieldArgs a) {
         // ---- head (last unit of the sequence).  Behind its barrier: layer-0 unit 0 streams in for the next group, the
         // next tile's position is finished and its 32 lookups are issued -- they fly under the head's MFMAs.
         {
-            const f16x8* unit = unit_begin();
+            const f16x8* unit = unit_begin(Younger<16>{});      // the last matrix' tiles NT-2 and NT-1
             float nx, ny, nz;                                   // without a next group: this tile again (harmless, keeps `it` dead above)
             tile_point_finish(a, tn.b, tn.nn, raw_next, tn.valid, h, has_next, nx, ny, nz);
             input_tile_issue_volume(a, tn.b, 0, nx, ny, nz, h, it);
