@@ -202,7 +202,7 @@ def sample_composite_pass(args, gen, fvol, glob, cam, meta, evs):
             if i == 2:
                 evs.record(ev[0])
             for p in pts:               # the lookups of the coarse and of the fine pass, as the fused kernels make them
-                ops.gather_features(gen.siren, fcl, p, R, S)
+                ops.gather_features(gen.siren, fcl, p)
         evs.record(ev[1])
         for i in range(reps + 2):
             if i == 2:

@@ -15,7 +15,6 @@
 #include "cnerf_dev.hpp"
 #include "cnerf_kernels.hpp"
 #include "field_common.hpp"
-#include "patch_box.hpp"
 
 namespace cnerf {
 
@@ -238,9 +237,6 @@ struct Chain16Args {
     _Float16* go16;           // TB16 (tiles, 1, 32, 32)
     unsigned int* gmax;       // dry run: per slab the bits of max |ga| (non-negative floats order like their bits), then max |go'|
     unsigned int* sat;        // chain run, optional: += 1 per (tile, slab) whose stored gradients left fp16's range and were clamped
-    float* dfeat;             // chain run, optional: (points of the chunk, 32 * n_in) fp32 row-major, image-major like grad_out: d loss / d (layer-0
-                              // input) of every point is STORED here instead of being scattered into the gradient volume by this kernel --
-                              // scatter_patch_kernel then adds it to the volume patch by patch with the coinciding corners pre-reduced in LDS
     int nslab;
     int group_step;           // process every group_step-th tile group of a block's range (dry-run sampling)
     unsigned char slab_kind[C16_MAX_SLABS];   // per slab: C16_FILM / C16_SINE / C16_RES_FC1 / C16_RES_FC2
@@ -574,15 +570,6 @@ __global__ __launch_bounds__(256) void chain16_kernel(Chain16Args A) {
 #pragma unroll
                 for (int c = 0; c < KCH; ++c)
                     z = __builtin_amdgcn_mfma_f32_32x32x16_f16(unit[(sub * KCH + c) * 64 + lane], __builtin_bit_cast(f16x8, frag_in[c]), z, 0, 0, 0);
-                if (A.dfeat) {                  // (wave-uniform) the volume scatter is a kernel of its own: leave the 32 gradients of the point
-                    if (valid) {
-                        float* d = A.dfeat + gpt * (size_t)(32 * a.n_in) + 32 * tk + 4 * h;
-#pragma unroll
-                        for (int gq = 0; gq < 4; ++gq)
-                            *reinterpret_cast<f32x4*>(d + 8 * gq) = f32x4{z[4 * gq] * U0, z[4 * gq + 1] * U0, z[4 * gq + 2] * U0, z[4 * gq + 3] * U0};
-                    }
-                    continue;
-                }
                 const int V = a.lvl_V[lvl], C = a.lvl_C[lvl];
                 Corner8 cr;
                 trilinear_corners(px, py, pz, a.half_voxel, V, cr);
@@ -734,7 +721,6 @@ struct Chain16Launch {
     void* go16;
     unsigned int* gmax;
     unsigned int* sat;
-    float* dfeat;
     int nslab, dry, group_step;
 };
 
@@ -770,7 +756,6 @@ static hipError_t launch_chain16_nt(const FieldArgs& f, const Chain16Launch& c, 
     A.go16 = (_Float16*)c.go16;
     A.gmax = c.gmax;
     A.sat = c.sat;
-    A.dfeat = c.dfeat;
     A.nslab = c.nslab;
     A.group_step = c.group_step < 1 ? 1 : c.group_step;
     if (!slab_kinds_of(f, A.slab_kind, c.nslab)) return hipErrorInvalidValue;
@@ -790,8 +775,8 @@ static hipError_t launch_chain16_nt(const FieldArgs& f, const Chain16Launch& c, 
 }
 
 hipError_t launch_chain16(const FieldArgs& f, int H, const void* units, const void* head_t, const float* winv, const float* scales, const void* cos16,
-                          void* g16, void* go16, unsigned int* gmax, unsigned int* sat, float* dfeat, int nslab, int dry, int group_step, hipStream_t stream) {
-    const Chain16Launch c{units, head_t, winv, scales, cos16, g16, go16, gmax, sat, dfeat, nslab, dry, group_step};
+                          void* g16, void* go16, unsigned int* gmax, unsigned int* sat, int nslab, int dry, int group_step, hipStream_t stream) {
+    const Chain16Launch c{units, head_t, winv, scales, cos16, g16, go16, gmax, sat, nslab, dry, group_step};
     bool res = false;
     for (int l = 0; l < f.L; ++l) res |= f.layer_kind[l] == CNERF_LAYER_RES;
 #define C16_CASE(NT_)                                                                                                                   \
@@ -805,110 +790,6 @@ hipError_t launch_chain16(const FieldArgs& f, int H, const void* units, const vo
         default: return hipErrorInvalidValue;
     }
 #undef C16_CASE
-}
-
-// =====================================================================================================================
-// scatter_patch: d loss / d (looked-up feature) of every sample point -> the gradient volume (adjoint of the trilinear lookup)
-// =====================================================================================================================
-// The chain kernel leaves the 32-channel gradient of every point and input tile in `dfeat` (fp32, row-major per point); this
-// kernel adds w_k * g to the 8 corner voxels of every point.  Done point by point that is 1 KiB of float atomics per point
-// -- 13 ms of a batch-8 training step at the chip's memory-side atomic rate (1.3 TB/s), the largest single item of the
-// half-precision backward in round 2.  Most of those bytes coincide: neighbouring pixels at the same depth are ~0.4 voxel apart.
-// So a wave takes a PATCH of 4 x 4 pixels x 2 depths (32 points; the visiting order of gather_patch_kernel -- the points are
-// addressed through dfeat's row index, so any order is as good as any other for the chain), finds the distinct voxels among
-// its 256 (point, corner) pairs -- typically 20-40 -- accumulates into one 128-byte line per distinct voxel in LDS
-// (ds_add_f32) and flushes each line ONCE with line-shaped atomics (two voxels x 32 channels per wave instruction).
-// Distinct voxels are found without sorting (patch_box.hpp).  A patch whose box is larger than 6 x 6 x 6, or with more than 64
-// distinct voxels (grazing rays, huge volumes), and shapes the patch does not divide, take the direct route: 8 atomics per point.  Sums are fp32 either way; like every atomic
-// accumulation the order of the additions (hence the last bits) is not deterministic.
-struct ScatterPatchArgs {
-    FieldArgs f;              // geometry, mode (coarse / fine / points), positions' sources, gradient volumes, input tiles
-    const float* dfeat;       // (B * n_per_image, 32 * n_in)
-    int patch;                // 1: R % 4 == 0 && S % 2 == 0 and the points are a render's samples -> patch order, else linear
-};
-__global__ __launch_bounds__(256) void scatter_patch_kernel(ScatterPatchArgs A) {
-    const FieldArgs& a = A.f;
-    __shared__ float s_acc[4][PB_SLOTS * 32];       // one 32-channel line per distinct voxel
-    __shared__ int s_key[4][32 * 8];                // box-local key of (point, corner); -1: zero weight, nothing to add
-    __shared__ float s_w[4][32 * 8];
-    __shared__ int s_slot[4][256];                  // key -> compact slot number
-    __shared__ int s_vox[4][PB_SLOTS];              // slot -> voxel index
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int j = lane & 31, h = lane >> 5, ch = lane & 31;
-    float* acc = s_acc[wave];
-    int* key = s_key[wave];
-    float* sw = s_w[wave];
-    int* slot = s_slot[wave];
-    int* svox = s_vox[wave];
-
-    const long long tpi = a.tiles_per_image, total = a.total_tiles;
-    const int cls = blockIdx.x & 7, idx_in_cls = blockIdx.x >> 3;
-    const int blk_per_cls = (gridDim.x + 7 - cls) / 8;
-    const long long t_end = total * (cls + 1) / 8;
-    const int R = a.geom.R, S = a.geom.S;
-    const bool patch = A.patch != 0;
-    for (long long t0 = total * cls / 8 + (long long)idx_in_cls * 4; t0 < t_end; t0 += (long long)blk_per_cls * 4) {
-        const long long t = t0 + wave;
-        if (t >= t_end) continue;                                       // wave-uniform (there is no block-level barrier below)
-        const int b = (int)(t / tpi);
-        const long long ti = t - (long long)b * tpi;
-        const long long n = patch_point(patch, ti, j, R, S);
-        const bool valid = n < a.n_per_image;
-        const long long nn = valid ? n : a.n_per_image - 1;
-        float px, py, pz;
-        tile_point(a, b, nn, valid, h, false, px, py, pz);
-        for (int tk = 0; tk < a.n_in; ++tk) {
-            const int lvl = a.in_level[tk];
-            if (lvl < 0) continue;                                      // the xyz tile: no gradient flows to the sample positions
-            const int V = a.lvl_V[lvl], C = a.lvl_C[lvl];
-            Corner8 cr;
-            int lo[3], hi[3];
-            trilinear_corners(px, py, pz, a.half_voxel, V, cr, lo, hi);
-            float* gv = a.lvl_grad[lvl] + (size_t)b * V * V * V * C + a.in_chan[tk];
-            const PatchBox pb = patch_box_build<true>(cr, lo, hi, valid, V, lane, key, sw, slot, svox);
-            if (pb.reducible) {
-                for (int i = lane; i < pb.U * 32; i += WAVE) acc[i] = 0.0f;
-                pb_wave_sync();
-            }
-            // two points per wave instruction, 32 channels each
-#pragma unroll 2
-            for (int pp = 0; pp < 16; ++pp) {
-                const int p = 2 * pp + h;
-                const long long np = patch_point(patch, ti, p, R, S);           // rows of dfeat are addressed per point
-                const float gval = np < a.n_per_image ? A.dfeat[((size_t)b * a.n_per_image + np) * (size_t)(32 * a.n_in) + 32 * tk + ch] : 0.0f;
-                const f32x4 w0 = *reinterpret_cast<const f32x4*>(sw + p * 8), w1 = *reinterpret_cast<const f32x4*>(sw + p * 8 + 4);
-                const u32x4 k0 = *reinterpret_cast<const u32x4*>(key + p * 8), k1 = *reinterpret_cast<const u32x4*>(key + p * 8 + 4);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int ka = (int)k0[k], kb = (int)k1[k];
-                    if (pb.reducible) {
-                        if (ka >= 0) atomicAdd(acc + slot[ka] * 32 + ch, gval * w0[k]);
-                        if (kb >= 0) atomicAdd(acc + slot[kb] * 32 + ch, gval * w1[k]);
-                    } else {             // too large a box / too many distinct voxels: straight to memory
-                        if (ka >= 0) atomicAdd(gv + (size_t)(pb.boxed ? pb_voxel_of_key(pb, ka, V) : ka) * C + ch, gval * w0[k]);
-                        if (kb >= 0) atomicAdd(gv + (size_t)(pb.boxed ? pb_voxel_of_key(pb, kb, V) : kb) * C + ch, gval * w1[k]);
-                    }
-                }
-            }
-            pb_wave_sync();
-            if (pb.reducible)               // every distinct voxel's line once: two voxels x 32 channels per wave instruction
-                for (int s2 = h; s2 < pb.U; s2 += 2) atomicAdd(gv + (size_t)svox[s2] * C + ch, acc[s2 * 32 + ch]);
-            pb_wave_sync();
-        }
-    }
-}
-
-hipError_t launch_scatter_patch(const FieldArgs& f, const float* dfeat, hipStream_t stream) {
-    ScatterPatchArgs A;
-    A.f = f;
-    A.dfeat = dfeat;
-    A.patch = (f.mode != FIELD_MODE_POINTS && f.geom.R % 4 == 0 && f.geom.S % 2 == 0 && (long long)f.geom.R * f.geom.R * f.geom.S == f.n_per_image) ? 1 : 0;
-    long long blocks = (f.total_tiles + 3) / 4;
-    if (blocks > 256 * 12) blocks = 256 * 12;
-    if (blocks < 8) blocks = 8;
-    blocks = (blocks + 7) / 8 * 8;
-    hipLaunchKernelGGL(scatter_patch_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, A);
-    return hipGetLastError();
 }
 
 }  // namespace cnerf

@@ -387,9 +387,6 @@ int cnerf_gather_features(const cnerf_cfg* cfg, const float* fvol_cl, const floa
     if (!fvol_cl || !points || !feat || n_per_image < 1) return fail(CNERF_EINVAL, "gather_features: bad argument");
     if (cfg->C != 32 || cfg->n_levels > 1) return fail(CNERF_EINVAL, "gather_features: single 32-channel volume only");
     GatherArgs a{fvol_cl, points, feat, (long long)n_per_image, cfg->B, cfg->V, cfg->C, cfg->voxel_length / 2.0f};
-    // cfg->R, cfg->S describe the points' order when they are the samples of a render (n_per_image = R * R * S, ray-major): a
-    // visiting-order hint for the kernel's cache reuse, never a change of results
-    if ((long long)cfg->R * cfg->R * cfg->S == n_per_image) a.R = cfg->R, a.S = cfg->S;
     if (hipError_t e = launch_gather(a, (hipStream_t)stream)) return hip_fail(e, "gather");
     return CNERF_OK;
 }
@@ -772,7 +769,7 @@ int field_backward16_impl(const cnerf_cfg* cfg, uint32_t mode, int32_t group_ste
                           const float* phase, const float* cam2world, const float* u_strat, const float* fine_z,
                           const float* grad_rgb_sigma, const float* saved_rgb_sigma, void* act_feat16, void* act_h16, void* act_c16,
                           void* act_g16, void* act_go16, const float* scales, uint32_t* gmax, const cnerf_grad_volumes* grad_vols,
-                          uint32_t* sat, float* dfeat, void* stream_) {
+                          uint32_t* sat, void* stream_) {
     g_err[0] = 0;
     if (int rc = check_cfg(cfg, true)) return rc;
     Chain16Layout l;
@@ -827,18 +824,14 @@ int field_backward16_impl(const cnerf_cfg* cfg, uint32_t mode, int32_t group_ste
     fa.saved_out = saved_rgb_sigma ? saved_rgb_sigma + (size_t)image0 * npi * 4 : nullptr;
     const float* winv = (const float*)(base16 + l.winv_off);
     if (mode & CNERF_B16_DRY) {
-        if (hipError_t e = launch_chain16(fa, cfg->H, base16, base16 + l.head_off, winv, scales, act_c16, nullptr, nullptr, gmax, nullptr, nullptr, l.n_mats, 1,
+        if (hipError_t e = launch_chain16(fa, cfg->H, base16, base16 + l.head_off, winv, scales, act_c16, nullptr, nullptr, gmax, nullptr, l.n_mats, 1,
                                           group_step < 1 ? 1 : group_step, stream))
             return hip_fail(e, "chain16 (dry run)");
     }
     if (mode & CNERF_B16_CHAIN) {
-        // dfeat given: the chain stores d loss / d (layer-0 input) per point and the volume scatter runs as its own kernel, patch by
-        // patch with coinciding corners pre-reduced in LDS (bwd16.hip, scatter_patch_kernel); else the chain scatters point by point
-        if (hipError_t e = launch_chain16(fa, cfg->H, base16, base16 + l.head_off, winv, scales, act_c16, act_g16, act_go16, nullptr, sat, dfeat, l.n_mats, 0, 1,
+        if (hipError_t e = launch_chain16(fa, cfg->H, base16, base16 + l.head_off, winv, scales, act_c16, act_g16, act_go16, nullptr, sat, l.n_mats, 0, 1,
                                           stream))
             return hip_fail(e, "chain16");
-        if (dfeat)
-            if (hipError_t e = launch_scatter_patch(fa, dfeat, stream)) return hip_fail(e, "scatter_patch");
     }
     return CNERF_OK;
 }
@@ -852,7 +845,7 @@ int cnerf_field_backward16(const cnerf_cfg* cfg, uint32_t mode, int32_t group_st
                            void* stream_) {
     return field_backward16_impl(cfg, mode, group_step, pass, image0, n_images, vols, packed, packed16, freq, phase, cam2world, u_strat, fine_z,
                                  grad_rgb_sigma, saved_rgb_sigma, act_feat16, act_h16, act_c16, act_g16, act_go16, scales, gmax, grad_vols, nullptr,
-                                 nullptr, stream_);
+                                 stream_);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -866,7 +859,6 @@ struct BackwardLayout {
     size_t a_feat, a_h, a_c, a_g, a_go;              // chunk buffers (a_feat / a_h / a_c absent when the forward kept its activations)
     size_t gmax, scales;                             // fp16: sampled maxima (n_mats + 1 uint32), {S, 1/S} pairs (n_mats + 1)
     size_t dwarg, cs, dwh, csh;                      // per-image reductions of one matrix: (cnt, H, 32 * max tiles), (cnt, H), (cnt, 4, H), (cnt, 4)
-    size_t dfeat;                                    // fp16: d loss / d (layer-0 input) per point, (n, 32 * n_in) fp32, between the chain and the scatter
     size_t total;
     int n_mats, n_in, k0;
 };
@@ -910,7 +902,6 @@ int backward_layout(const cnerf_cfg* c, int bprec, int cnt, bool have_act16, Bac
     L.cs = take((size_t)cnt * H * sizeof(float));
     L.dwh = take((size_t)cnt * 4 * H * sizeof(float));
     L.csh = take((size_t)cnt * 4 * sizeof(float));
-    L.dfeat = take(bprec == CNERF_PREC_FP16 ? n * 32 * L.n_in * sizeof(float) : 0);
     L.total = off;
     return CNERF_OK;
 }
@@ -1019,12 +1010,11 @@ int cnerf_render_backward(const cnerf_cfg* cfg, int32_t bprec, int32_t cnt_max, 
                 step = step < 1 ? 1 : (step > 16 ? 16 : step);
                 if (int rc = field_backward16_impl(cfg, (have_act16 ? 0u : CNERF_B16_STORE) | CNERF_B16_DRY, (int)step, pass, b0, cnt, vols, packed, packed_bwd,
                                                    freq, phase, cam2world, rng->u_strat, saved->fine_z, g_out, s_out, a_feat, a_h, a_c, a_g, a_go, scales, gmax,
-                                                   grad_vols, nullptr, nullptr, stream_))
+                                                   grad_vols, nullptr, stream_))
                     return rc;
                 if (hipError_t e = launch_pow2_scales(gmax, L.n_mats, scales, stream)) return hip_fail(e, "pow2_scales");
                 if (int rc = field_backward16_impl(cfg, CNERF_B16_CHAIN, 1, pass, b0, cnt, vols, packed, packed_bwd, freq, phase, cam2world, rng->u_strat,
-                                                   saved->fine_z, g_out, s_out, a_feat, a_h, a_c, a_g, a_go, scales, gmax, grad_vols, saturated,
-                                                   (float*)(ws + L.dfeat), stream_))
+                                                   saved->fine_z, g_out, s_out, a_feat, a_h, a_c, a_g, a_go, scales, gmax, grad_vols, saturated, stream_))
                     return rc;
                 const size_t slab = (size_t)T * NT * 2048;             // bytes per matrix in a_h / a_g
                 for (int m = 0; m < L.n_mats; ++m) {

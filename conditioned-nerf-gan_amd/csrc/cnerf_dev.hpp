@@ -269,19 +269,13 @@ __device__ __forceinline__ void unnormalize(float p, float half_voxel, int V, in
     hi = (fl + 1.0f) - ic;
 }
 
-// lo[3] / hi[3]: voxel coordinates (x, y, z) of the floor corner and of the far corner (clamped to V - 1) -- corner k sits at
-// (k & 1 ? hi[0] : lo[0], k & 2 ? hi[1] : lo[1], k & 4 ? hi[2] : lo[2])
-__device__ __forceinline__ void trilinear_corners(float px, float py, float pz, float half_voxel, int V, Corner8& c, int* lo = nullptr, int* hi = nullptr) {
+__device__ __forceinline__ void trilinear_corners(float px, float py, float pz, float half_voxel, int V, Corner8& c) {
     int ix, iy, iz;
     float lx, hx, ly, hy, lz, hz;
     unnormalize(px, half_voxel, V, ix, lx, hx);
     unnormalize(py, half_voxel, V, iy, ly, hy);
     unnormalize(pz, half_voxel, V, iz, lz, hz);
     const int ix1 = min(ix + 1, V - 1), iy1 = min(iy + 1, V - 1), iz1 = min(iz + 1, V - 1);
-    if (lo) {
-        lo[0] = ix; lo[1] = iy; lo[2] = iz;
-        hi[0] = ix1; hi[1] = iy1; hi[2] = iz1;
-    }
     // a +1 corner that would fall at index V only occurs with weight exactly 0 (coordinate clamped to V-1), so
     // re-reading the clamped voxel adds +0 where ATen skips the term.
 #pragma unroll

@@ -170,7 +170,6 @@ struct GatherArgs {
     long long n_per_image;
     int B, V, C;
     float half_voxel;
-    int R = 0, S = 0;     // > 0: the points are the samples of R x R rays x S depths per image, ray-major (a visiting-order hint only)
 };
 hipError_t launch_gather(const GatherArgs& a, hipStream_t stream);
 hipError_t launch_scatter(const GatherArgs& a, const float* grad_feat, float* grad_fvol, hipStream_t stream);
@@ -189,8 +188,7 @@ hipError_t launch_pack_t16(const float* w, int n_rows_w, int n_cols_w, int n_col
 hipError_t launch_col_abs_sum_max(const float* w, int n_rows, int n_cols, float* slot, hipStream_t stream);
 hipError_t launch_pack_head_t16(const float* w, int H, void* dst, float* winv_slot, uint32_t* wmax_slot, hipStream_t stream);
 hipError_t launch_chain16(const FieldArgs& f, int H, const void* units, const void* head_t, const float* winv, const float* scales, const void* cos16,
-                          void* g16, void* go16, unsigned int* gmax, unsigned int* sat, float* dfeat, int nslab, int dry, int group_step, hipStream_t stream);
-hipError_t launch_scatter_patch(const FieldArgs& f, const float* dfeat, hipStream_t stream);
+                          void* g16, void* go16, unsigned int* gmax, unsigned int* sat, int nslab, int dry, int group_step, hipStream_t stream);
 hipError_t launch_weight_grad16(int cnt, long long tiles_per_image, int n_rows, int g_ct, int x_ct, const void* G, const void* X, float* dW,
                                 float* colsum, const float* inv_scale, hipStream_t stream);
 

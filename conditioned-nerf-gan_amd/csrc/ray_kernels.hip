@@ -7,7 +7,6 @@
 // distance2depth volumetric_rendering.py:345-356) and F.grid_sample + permute (siren.py:555-571).
 #include "cnerf_dev.hpp"
 #include "cnerf_kernels.hpp"
-#include "patch_box.hpp"
 
 namespace cnerf {
 
@@ -558,79 +557,14 @@ __global__ __launch_bounds__(256) void gather_kernel(GatherArgs a) {
     for (long long pt = pr.begin; pt < pr.end; pt += pr.stride) gather_point(a, pt, sub);
 }
 
-// The same lookup with the points of a render visited patch by patch and every distinct corner line fetched ONCE.  When the caller
-// says the points are the samples of R x R rays x S depths in ray-major order (GatherArgs::R, S), a wave takes a patch of 4 x 4
-// neighbouring pixels x 2 consecutive depths (32 points) instead of 32 consecutive samples of one ray: consecutive samples of a ray
-// are ~1.4 voxels apart and share next to no corner lines, neighbouring pixels are ~0.4 voxel apart at the same depth, so the 256
-// corner lines of the patch are 20-40 distinct ones.  Counters of the point-by-point kernel (profiles/r03_gather_counters.md): 1 KiB
-// per point goes through the texture addresser and the vector L1, half of it misses to L2 at 255 cycles average round trip, the L1
-// stalls on pending misses for 42 % of its active cycles -- the kernel is bound by L1 miss handling, with HBM traffic already within
-// 1.2x of compulsory.  Merely visiting the points in patch order did not help (the duplicates are in flight together and each
-// still takes its own trip to L2: 1.23 -> 1.34 ms).  So the duplicates are removed before they are requested: the distinct voxels
-// of the patch are numbered (patch_box.hpp), each line is loaded once into LDS (8 lanes x 16 bytes per line, 8 lines per wave
-// instruction), and the 8 corners of every point are read from there (ds_read_b128, 128 B/clk).  The arithmetic per point is
-// gather_point's, operand for operand: results are bit-identical.  Tiles that are not reducible fall back to gather_point.
-__global__ __launch_bounds__(256) void gather_box_kernel(GatherArgs a) {
-    __shared__ f32x4 s_line[4][PB_SLOTS * 8];       // one 128-byte line per distinct voxel
-    __shared__ int s_key[4][32 * 8];
-    __shared__ float s_w[4][32 * 8];
-    __shared__ int s_slot[4][256];
-    __shared__ int s_vox[4][PB_SLOTS];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int j = lane & 31, sub = lane & 7, q8 = lane >> 3;
-    f32x4* line = s_line[wave];
-    int* key = s_key[wave];
-    float* sw = s_w[wave];
-    int* slot = s_slot[wave];
-    int* svox = s_vox[wave];
-    const long long tpi = a.n_per_image / 32, total = tpi * a.B;      // (patch shapes: n_per_image is a multiple of 32)
-    const int cls = blockIdx.x & 7, idx_in_cls = blockIdx.x >> 3;
-    const int blk_per_cls = (gridDim.x + 7 - cls) / 8;
-    const long long t_end = total * (cls + 1) / 8;
-    for (long long t0 = total * cls / 8 + (long long)idx_in_cls * 4; t0 < t_end; t0 += (long long)blk_per_cls * 4) {
-        const long long t = t0 + wave;
-        if (t >= t_end) continue;                                     // wave-uniform
-        const long long b = t / tpi, ti = t - b * tpi;
-        const long long pt_j = b * a.n_per_image + patch_point(true, ti, j, a.R, a.S);
-        const float* pj = a.points + pt_j * 3;
-        Corner8 cr;
-        int lo[3], hi[3];
-        trilinear_corners(__builtin_nontemporal_load(pj), __builtin_nontemporal_load(pj + 1), __builtin_nontemporal_load(pj + 2), a.half_voxel, a.V, cr, lo, hi);
-        const PatchBox pb = patch_box_build<false>(cr, lo, hi, true, a.V, lane, key, sw, slot, svox);
-        const float* vol = a.fvol + (size_t)b * a.V * a.V * a.V * 32 + 4 * sub;
-        if (!pb.reducible) {            // grazing rays / very fine grids: point by point
-#pragma unroll 1
-            for (int it = 0; it < 4; ++it) gather_point(a, b * a.n_per_image + patch_point(true, ti, it * 8 + q8, a.R, a.S), sub);
-            pb_wave_sync();
-            continue;
-        }
-        // every distinct line once: 8 lines per wave instruction, 8 lanes x 16 bytes each
-        for (int s0 = 0; s0 < pb.U; s0 += 8) {
-            const int sl = s0 + q8;
-            if (sl < pb.U) line[sl * 8 + sub] = *reinterpret_cast<const f32x4*>(vol + (size_t)svox[sl] * 32);
-        }
-        pb_wave_sync();
-#pragma unroll 1
-        for (int it = 0; it < 4; ++it) {
-            const int p = it * 8 + q8;
-            f32x4 q[8];
-            float w[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                q[k] = line[slot[key[p * 8 + k]] * 8 + sub];
-                w[k] = sw[p * 8 + k];
-            }
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int k = 0; k < 8; ++k)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[e] = acc[e] + q[k][e] * w[k];
-            const long long pt = b * a.n_per_image + patch_point(true, ti, p, a.R, a.S);
-            __builtin_nontemporal_store(acc, reinterpret_cast<f32x4*>(a.feat + pt * 32 + 4 * sub));
-        }
-        pb_wave_sync();                 // the next tile overwrites the wave's tables
-    }
-}
+// Round 3 measured two re-orderings of this kernel and kept neither (profiles/r03_gather_counters.md): visiting a render's samples
+// patch by patch (4 x 4 pixels x 2 depths per block iteration, so that the repeated corner lines of neighbouring pixels would hit
+// in L1) 1.23 -> 1.29-1.37 ms per 16.8 M lookups -- the duplicates are in flight together and each still takes its own trip to L2;
+// and fetching every distinct corner line of such a patch once into LDS (box-local voxel keys, wave prefix sum for compact slots)
+// 1.19 -> 1.54 ms -- a patch has 30-70 distinct lines, not the 20-40 first estimated, and the dependent phases of a tile (positions,
+// box, lines, corners) run at 12 waves per CU instead of streaming at full occupancy.  Counters of this kernel: HBM-side traffic
+// within 1.1x of compulsory, 1 KiB per point through the texture addresser at 42 % of its rate, half the corner lines miss L1
+// at 255 cycles average L2 round trip, the L1 stalled on pending misses for 42 % of its active cycles.
 
 // Adjoint of gather_kernel: grad_fvol[corner k of point] += w_k * grad_feat[point] (8 lanes per point, 4 channels each, so
 // the 8 lanes of a point add one whole 128-B corner line per atomic instruction).  Used by the backward of the per-point
@@ -698,15 +632,6 @@ hipError_t launch_transpose_cl(int B, int C, int V, const float* src, float* dst
 }
 hipError_t launch_gather(const GatherArgs& a, hipStream_t stream) {
     const long long total = (long long)a.B * a.n_per_image;
-    // a render's samples (R x R rays x S depths, ray-major) whose shape the 4 x 4 x 2 patch divides: patch by patch, distinct lines once
-    if (a.R > 0 && a.S > 0 && a.R % 4 == 0 && a.S % 2 == 0 && (long long)a.R * a.R * a.S == a.n_per_image) {
-        long long blocks = total / 32 / 4;
-        if (blocks > 256 * 12) blocks = 256 * 12;
-        if (blocks < 8) blocks = 8;
-        blocks = (blocks + 7) / 8 * 8;
-        hipLaunchKernelGGL(gather_box_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a);
-        return hipGetLastError();
-    }
     long long blocks = (total + 31) / 32;
     if (blocks > 256 * 16) blocks = 256 * 16;
     blocks = (blocks + 7) / 8 * 8;                    // every XCD class owns an eighth of the points

@@ -181,12 +181,10 @@ def channel_first(fvol_cl):
     return out
 
 
-def gather_features(net, fvol_cl, points, img_size=None, num_steps=None):
-    """Trilinear lookup only.  img_size / num_steps: say so when the points are the samples of a render (img_size^2 rays x num_steps
-    depths per image, ray-major): the kernel then visits them patch by patch (neighbouring pixels share corner lines) -- same results."""
+def gather_features(net, fvol_cl, points):
     points = _f32(points)
     B, n = points.shape[0], points.shape[1]
-    cfg = make_cfg(net, B, int(fvol_cl.shape[1]), *((int(img_size), int(num_steps)) if img_size and num_steps else ()))
+    cfg = make_cfg(net, B, int(fvol_cl.shape[1]))
     out = torch.empty((B, n, fvol_cl.shape[-1]), dtype=torch.float32, device=points.device)
     L.check(L.lib().cnerf_gather_features(C.byref(cfg), L.ptr(fvol_cl), L.ptr(points), n, L.ptr(out), _stream()),
             "cnerf_gather_features")

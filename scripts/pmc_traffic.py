@@ -12,7 +12,7 @@ import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 POINTS = {"void cnerf::field_tile_kernel": 2 * 128 * 128 * 64, "void cnerf::h3::field_h3_kernel": 2 * 128 * 128 * 64,
-          "cnerf::gather_kernel": 2 * 128 * 128 * 64, "void cnerf::gather_patch_kernel": 2 * 128 * 128 * 64, "cnerf::composite_kernel": 2 * 2 * 128 * 128 * 64,
+          "cnerf::gather_kernel": 2 * 128 * 128 * 64, "cnerf::composite_kernel": 2 * 2 * 128 * 128 * 64,
           "cnerf::resample_kernel": 2 * 128 * 128 * 64, "cnerf::merge_composite_kernel": 2 * 2 * 128 * 128 * 64}
 
 
@@ -36,7 +36,7 @@ def main():
             key = next((k for k in POINTS if name.startswith(k)), None)
             if key is None or name not in tabs["WRITE_SIZE"]:
                 continue
-            if prec == "unfused" and key not in ("cnerf::gather_kernel", "void cnerf::gather_patch_kernel", "cnerf::composite_kernel"):
+            if prec == "unfused" and key not in ("cnerf::gather_kernel", "cnerf::composite_kernel"):
                 continue                      # (that run's forward writes its sample points: not the benchmarked forward)
             if prec != "unfused" and "::field_" in key and ((prec == "fp32") != ("field_tile" in key)):
                 continue

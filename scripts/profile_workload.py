@@ -43,8 +43,8 @@ with torch.no_grad():
     zs = torch.gather(allz, -1, idx).reshape(B * R * R, 2 * S).contiguous()
     rss = torch.gather(allrs, -2, idx.unsqueeze(-1).expand(-1, -1, -1, 4)).reshape(B * R * R, 2 * S, 4).contiguous()
     for _ in range(calls):
-        for p in pts:       # CNERF_GATHER_HINT=0: without the (img_size, num_steps) hint -> the point-by-point kernel (A/B, scripts/pmc_gather.sh)
-            ops.gather_features(gen.siren, fcl, p, *((R, S) if os.environ.get("CNERF_GATHER_HINT", "1") == "1" else ()))
+        for p in pts:
+            ops.gather_features(gen.siren, fcl, p)
         ops.composite(rss, zs, None, 0.0, "relu", True, False)
 torch.cuda.synchronize()
 print("ok", float(px.mean()), float(dp.mean()), "points per field launch", B * R * R * S, "gather points per launch", pts[0].shape[0] * pts[0].shape[1])

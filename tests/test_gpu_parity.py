@@ -181,35 +181,6 @@ def test_trilinear_lookup_bit_exact(golden, dev, name):
     assert np.array_equal(feat, g["coarse_feat"][..., :32])      # level 0 of a pyramid / the single volume
 
 
-@pytest.mark.parametrize("shape", [(2, 8, 4, 9), (1, 16, 6, 5), (3, 12, 64, 17), (1, 5, 3, 4)])
-def test_lookup_patch_order_is_bit_identical(dev, shape):
-    """cnerf_gather_features told that its points are the samples of a render (cfg R, S) visits them patch by patch (neighbouring
-    pixels x a few depths per block iteration, csrc/ray_kernels.hip::gather_patch_kernel) -- a visiting order, never a different
-    result: equal bit for bit to the call without the hint (which the golden vectors pin to F.grid_sample), including shapes the
-    patch tiling does not divide (fallback to the linear order)."""
-    import cnerf_amd
-    from cnerf_amd.generators import ImplicitGenerator3d
-    B, R, S, V = shape
-    torch.manual_seed(R * S)
-    gen = ImplicitGenerator3d("SHORTSIREN_FG", 16, 32, 4, 64)
-    cl = torch.randn(B, V, V, V, 32, device=dev)
-    pts = (torch.rand(B, R * R * S, 3, device=dev) - 0.5) * 1.5           # some outside the +-0.6 cube: border clamp
-    a = cnerf_amd.ops.gather_features(gen.siren, cl, pts)
-    b = cnerf_amd.ops.gather_features(gen.siren, cl, pts, R, S)
-    assert torch.equal(a, b)
-    ref = torch.nn.functional.grid_sample(cl.permute(0, 4, 1, 2, 3), (pts / 0.6).reshape(B, 1, 1, -1, 3), mode="bilinear", align_corners=False,
-                                          padding_mode="border").reshape(B, 32, -1).permute(0, 2, 1)
-    assert (b - ref).abs().max().item() < 1e-4      # (torch's GPU kernel contracts to fma: not bit-identical, the CPU one is -- goldens)
-    # ray-like points (neighbouring pixels a fraction of a voxel apart, as in a render): the tiles are reducible -- distinct corner lines
-    # fetched once into LDS -- where the random points above take the kernel's point-by-point fallback
-    if R % 4 == 0 and S % 2 == 0:
-        rr, cc, ss = torch.meshgrid(torch.arange(R, device=dev), torch.arange(R, device=dev), torch.arange(S, device=dev), indexing="ij")
-        zz = (ss + torch.rand(R, R, S, device=dev)) / S
-        ray = torch.stack([(cc / R - 0.5) * 0.9 * (0.4 + zz), (rr / R - 0.5) * 0.9 * (0.4 + zz), zz * 1.3 - 0.65], -1).reshape(1, R * R * S, 3)
-        pts = (ray + 0.02 * torch.randn(B, 1, 3, device=dev)).contiguous()
-        assert torch.equal(cnerf_amd.ops.gather_features(gen.siren, cl, pts), cnerf_amd.ops.gather_features(gen.siren, cl, pts, R, S))
-
-
 @pytest.mark.parametrize("name", GOLDEN_NAMES)
 def test_field_network(golden, dev, name):
     """siren sub-API at the reference's own sample points: rgb and sigma within 1e-4 (scaled)."""
