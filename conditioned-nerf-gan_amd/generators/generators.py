@@ -31,6 +31,18 @@ def draw_rng(B, P, S, hierarchical, noise_std, dev):
 
 
 class ImplicitGenerator3d(nn.Module):
+    _instances = 0
+
+    def _philox_key(self):
+        """(seed, offset) of this forward's in-kernel draws: see __init__."""
+        if self._rng_step != self.step:
+            self._rng_step, self._rng_calls = self.step, 0
+        offset = ((int(self.step) & 0xFFFFFF) << 8) | (self._rng_calls & 0xFF)
+        self._rng_calls += 1
+        rank = torch.distributed.get_rank() if torch.distributed.is_available() and torch.distributed.is_initialized() else 0
+        seed = (torch.cuda.initial_seed() + 0x9E3779B97F4A7C15 * (self._rng_salt + 1) + 0xD1B54A32D192ED03 * rank) & 0xFFFFFFFFFFFFFFFF
+        return seed, offset
+
     def __init__(self, siren_type, z_dim, input_dim, output_dim, hidden_dim, drop_out=0):
         super().__init__()
         self.z_dim = z_dim
@@ -43,7 +55,14 @@ class ImplicitGenerator3d(nn.Module):
         # where the four random draws of a forward come from: "torch" (torch.rand / randn on the device in the reference's
         # order and shapes -- the default: the torch generator advances as it does there) or "philox" (in-kernel)
         self.rng_mode = "torch"
-        self._philox_calls = 0
+        # Key and counter of the in-kernel draws (rng_mode "philox", dropout decisions).  Key = torch's CUDA seed mixed with a salt that
+        # is different for every generator of the process (a teacher and a student under one seed must not draw the same streams) and
+        # with the rank of a distributed job (ranks seeded alike still draw their own).  Counter offset = (self.step, calls within
+        # that step): `step` is what checkpoints store (utils.py:467), so a resumed run continues the stream instead of replaying the
+        # draws of steps 0..k -- nothing else has to be persisted.
+        self._rng_salt = ImplicitGenerator3d._instances
+        ImplicitGenerator3d._instances += 1
+        self._rng_step, self._rng_calls = None, 0
 
     def set_device(self, device):
         self.device = device
@@ -67,17 +86,15 @@ class ImplicitGenerator3d(nn.Module):
         rng = kwargs.get("_rng")
         if rng is None:
             if self.rng_mode == "philox":
-                # draws generated inside the kernels (Philox4x32-10): no RNG kernels, no tensors; seeded from torch's CUDA seed,
-                # one counter value per forward of this module
-                rng = {"philox": (torch.cuda.initial_seed(), self._philox_calls)}
-                self._philox_calls += 1
+                # draws generated inside the kernels (Philox4x32-10): no RNG kernels, no tensors; keyed per module, one counter value
+                # per forward (see __init__)
+                rng = {"philox": self._philox_key()}
             else:
                 rng = draw_rng(B, R * R, S, bool(hierarchical_sample), noise_std, dev)
         if net.drop_out and net.training and "drop" not in rng:
             # dropout decisions are Philox draws inside the field kernels (or rng["drop_coarse"/"drop_fine"] bytes), keyed like
-            # the philox rng mode: torch's CUDA seed and one counter value per forward
-            rng = dict(rng, drop=(float(net.drop_out), rng.get("philox") or (torch.cuda.initial_seed(), net._drop_calls)))
-            net._drop_calls += 1
+            # the philox rng mode
+            rng = dict(rng, drop=(float(net.drop_out), rng.get("philox") or self._philox_key()))
         aux_out = kwargs.get("_aux")
         pixels, depth, aux = ops.render(net, fvol, freq, phase, cam2worlds, R, fov, ray_start, ray_end, S,
                                         bool(hierarchical_sample), clamp_mode, noise_std, white_back, last_back, rng,

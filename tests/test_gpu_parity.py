@@ -1198,10 +1198,24 @@ def test_in_kernel_philox_equals_injected_draws(dev, precision):
         p1, _ = gen((fvol, glob), cam, R, 49.13, 0.25, 1.95, S, True, clamp_mode="relu", nerf_noise=0.0)
         p2, _ = gen((fvol, glob), cam, R, 49.13, 0.25, 1.95, S, True, clamp_mode="relu", nerf_noise=0.0)
     assert not torch.equal(p1, p2)
-    gen._philox_calls -= 2
+    gen._rng_calls -= 2
     with torch.no_grad():
         p3, _ = gen((fvol, glob), cam, R, 49.13, 0.25, 1.95, S, True, clamp_mode="relu", nerf_noise=0.0)
     assert torch.equal(p1, p3)
+    # the counter follows generator.step (what a checkpoint stores): a resumed run continues the stream, it does not replay step 0's
+    # draws; and a second generator under the same seed (a frozen teacher next to its student) draws a stream of its own
+    gen.step = 7
+    with torch.no_grad():
+        p4, _ = gen((fvol, glob), cam, R, 49.13, 0.25, 1.95, S, True, clamp_mode="relu", nerf_noise=0.0)
+    assert not torch.equal(p4, p1) and not torch.equal(p4, p2)
+    import copy
+    twin = copy.deepcopy(gen)
+    twin._rng_salt = gen._rng_salt + 1            # what a second ImplicitGenerator3d(...) of the process gets
+    gen.step, twin.step = 0, 0
+    with torch.no_grad():
+        q1, _ = gen((fvol, glob), cam, R, 49.13, 0.25, 1.95, S, True, clamp_mode="relu", nerf_noise=0.0)
+        q2, _ = twin((fvol, glob), cam, R, 49.13, 0.25, 1.95, S, True, clamp_mode="relu", nerf_noise=0.0)
+    assert torch.equal(q1, p1) and not torch.equal(q2, q1)
 
 
 def _dropout_rng(g, dev):
@@ -1359,3 +1373,35 @@ def test_forward_replays_from_a_hip_graph(dev, precision):
     fresh = call()
     assert torch.equal(replayed[0], fresh[0]) and torch.equal(replayed[1], fresh[1])
     assert not torch.equal(replayed[0], eager[0])
+
+
+def test_half_precision_backward_reports_clamped_outliers(dev):
+    """The fp16 backward stores d loss / d (sine argument) scaled by a power of two per matrix that comes from a SAMPLED maximum (every
+    k-th tile group once there are >= 4096 of them: here 8192 groups, every 4th) with a factor 32 of headroom; anything beyond is
+    clamped to fp16's range.  That clamp must not be silent: cnerf_render_backward counts the (tile, matrix) blocks it
+    clamped in, ops.LAST_SATURATED / trainer.last["render_bwd_clamped_blocks"] surface the count.  A ray whose gradient is 1e12 x the
+    others', planted in a tile group the sample does not visit (group 1 of XCD class 0 = tiles 4..7 = rays 2, 3), is reported; the same
+    render without it reports nothing."""
+    import cnerf_amd
+    from cnerf_amd import ops
+    from cnerf_amd.generators import ImplicitGenerator3d
+    torch.manual_seed(3)
+    B, R, S, V, H = 1, 128, 64, 16, 64
+    gen = ImplicitGenerator3d("SHORTSIREN_FG", 32, 32, 4, H).to(dev)
+    gen.set_device(dev)
+    gen.siren.precision, gen.siren.backward_precision = "fp16x3", "fp16"
+    gen.train()
+    with torch.no_grad():
+        gen.siren.final_layer.weight[3] *= 20
+    fvol, glob = torch.randn(B, 32, V, V, V, device=dev), torch.randn(B, 32, device=dev)
+    cam = torch.eye(4, device=dev).unsqueeze(0).contiguous()
+    cam[:, 2, 3] = -1.0
+    counts = []
+    for plant in (0.0, 1e7):
+        fv = fvol.clone().requires_grad_(True)
+        gen.zero_grad()
+        px, dp = gen((fv, glob), cam, R, 49.13, 0.25, 1.95, S, True, clamp_mode="softplus", nerf_noise=0.0, white_back=True)
+        (px.square().mean() + dp.mean() + plant * px[0, :, 0, 2].sum()).backward()
+        counts.append(int(ops.LAST_SATURATED.item()))
+        assert torch.isfinite(fv.grad).all()
+    assert counts[0] == 0 and counts[1] > 0, counts
