@@ -167,7 +167,10 @@ hipError_t launch_weight_grad16(int cnt, long long tiles_per_image, int n_rows, 
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) != hipSuccess) dev = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
-    long long bpi = cus / cnt;
+    // blocks per image: one block per CU where a block is 8 waves (H = 256); narrow outputs (the head: one wave per block, 36 KiB of
+    // LDS) get several blocks per CU -- with 256 single-wave blocks the head's reduction read its 4.3 GB at 2 TB/s
+    const int per_cu = noc >= 4 ? 1 : (noc == 2 ? 2 : 4);
+    long long bpi = (long long)cus * per_cu / cnt;
     if (bpi > tiles_per_image) bpi = tiles_per_image;
     if (bpi < 1) bpi = 1;
     WeightGrad16Args a{(const _Float16*)G, (const _Float16*)X, dW, colsum, inv_scale, tiles_per_image, cnt, g_ct, x_ct, 0, 32 * x_ct, n_rows, (int)bpi};
