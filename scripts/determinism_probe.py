@@ -45,5 +45,21 @@ for it in range(reps):
             idx = ne.nonzero()
             print(f"run {it}: stage {k}: {int(ne.sum())} of {ne.numel()} elements differ; first indices {idx[:6].tolist()}; values {a[ne][:4].tolist()} vs {b[ne][:4].tolist()}", flush=True)
             bad = True
+            if k in ("coarse_rgb_sigma", "fine_rgb_sigma"):      # which 32-point tiles, which tile groups, whose turn in which block
+                pts = ne.reshape(-1, 4).any(-1).nonzero().flatten()
+                tiles = torch.unique(pts // 32)
+                tpi = R * R * S // 32
+                G = (tpi + 3) // 4
+                g = tiles // 4
+                cls = g * 8 // G
+                idx = g - (G * cls) // 8
+                nblk = 256
+                print(f"   {tiles.numel()} tiles in {torch.unique(g).numel()} groups; points per differing tile min/max "
+                      f"{int(torch.bincount((pts // 32 - tiles.min()).long()).clamp(min=0)[torch.bincount((pts // 32 - tiles.min()).long()) > 0].min())}/"
+                      f"{int(torch.bincount((pts // 32 - tiles.min()).long()).max())}")
+                print("   classes:", torch.bincount(cls.long(), minlength=8).tolist())
+                print("   iteration of the block (idx // 32):", torch.unique(idx // (nblk // 8), return_counts=True))
+                print("   block in class (idx % 32):", torch.bincount((idx % (nblk // 8)).long(), minlength=32).tolist())
+                print("   wave (tile % 4):", torch.bincount((tiles % 4).long(), minlength=4).tolist())
     if bad or it % 50 == 0 or it == reps - 1:
         print(f"run {it}: {'DIFFERS' if bad else 'identical'}", flush=True)
