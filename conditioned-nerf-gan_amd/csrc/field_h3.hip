@@ -505,8 +505,13 @@ __global__ __launch_bounds__(256) void field_h3_kernel(FieldArgs a) {
         dma_k = dma_k + 1 == n_units ? 0 : dma_k + 1;
         dma_slot = (dma_slot + 1) & (SLOTS - 1);
     };
-    // every wave, at the start of every unit.  Plain forward: __syncthreads() (its vmcnt(0) also lands the wave's share of the copy).
-    // Activation-storing forward: the barrier must NOT drain the activation stores in flight (an HBM write round trip at every unit:
+    // every wave, at the start of every unit: this wave's share of the unit's copy must have LANDED before the barrier publishes it.
+    // LDS-DMA copies are counted by vmcnt and the wait is written out: the release fence of __syncthreads() is NOT a reliable one --
+    // the compiler drains vmcnt there for the stores and loads it keeps score of, and it left this kernel's first hidden-layer
+    // barrier (and the layer-0 barrier of multi-tile inputs) without any wait: a block whose copy was slow -- the first tile group of a
+    // launch, weights cold in L2 -- then multiplied by a half-copied weight unit (round 3: test_full_size_properties differing between
+    // two runs in ~1 of 300 forwards, always whole tiles, almost always a block's first group).  Plain forward: wait for everything
+    // (the next tile's lookups are consumed right behind the layer-0 barrier anyway).  Activation-storing forward: the barrier must NOT drain the activation stores in flight (an HBM write round trip at every unit:
     // this alone made the storing forward 16.4 ms against 10.7 plain) -- lds_only_barrier() behind a counted wait.  YOUNGER = a lower
     // bound, known at every call site, on the vector-memory operations this wave has issued since it requested the copy of the unit
     // it is about to read (the request of the previous unit_begin): the activation stores of the epilogues in between, 8 per output
@@ -515,6 +520,7 @@ __global__ __launch_bounds__(256) void field_h3_kernel(FieldArgs a) {
     auto unit_begin = [&](auto younger_tag) -> const f16x8* {
         constexpr int YOUNGER = decltype(younger_tag)::value;
         if constexpr (STORE == STORE_NONE) {
+            wait_vmcnt<0>();
             __syncthreads();
         } else {
             if (YOUNGER >= 16 && store_live) wait_vmcnt<16>();
@@ -746,7 +752,8 @@ __global__ __launch_bounds__(256) void field_h3_kernel(FieldArgs a) {
         }
         BSTAMP(5);
     }
-    __syncthreads();                                                 // drain the copies issued for tiles this block does not have
+    wait_vmcnt<0>();                                                 // drain the copies issued for tiles this block does not have: an LDS-DMA
+    __syncthreads();                                                 // write must not land after the block has given its LDS back
 #ifdef CNERF_STAMPS
     if (a.stamps && lane == 0)
         for (int i = 0; i < 8; ++i) atomicAdd(a.stamps + i, st_[i]);

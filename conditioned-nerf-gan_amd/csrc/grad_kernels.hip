@@ -91,7 +91,8 @@ __global__ __launch_bounds__(256) void weight_grad_kernel(WeightGradArgs a) {
     if (s_begin < s_end) dma_stage(s_begin, 0);
     int cur = 0;
     for (long long s = s_begin; s < s_end; ++s) {
-        __syncthreads();                                           // stage s has landed; the other buffer is free
+        wait_vmcnt<0>();                                           // this wave's LDS-DMA pieces of stage s have landed (written out: the fence of
+        __syncthreads();                                           // __syncthreads() is not a reliable wait for LDS-DMA) ... and everybody's; the other buffer is free
         if (s + 1 < s_end) dma_stage(s + 1, cur ^ 1);
         if (active) {
             const float* xs = ldsf + (size_t)cur * STAGE_F4 * 4 + p * K + c;
