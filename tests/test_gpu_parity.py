@@ -1405,3 +1405,35 @@ def test_half_precision_backward_reports_clamped_outliers(dev):
         counts.append(int(ops.LAST_SATURATED.item()))
         assert torch.isfinite(fv.grad).all()
     assert counts[0] == 0 and counts[1] > 0, counts
+
+
+@pytest.mark.parametrize("precision", ["fp16x3", "fp16", "fp32"])
+def test_forward_is_deterministic_over_many_launches(dev, precision):
+    """Forty forwards of the same inputs and draws, a fresh network (fresh weight buffers: cold in L2 at its first launch) every ten, must
+    agree bit for bit.  Regression test of round 3's find: the fp16 kernels publish their weight units -- LDS-DMA copies -- to the block
+    behind a barrier, and the copy's completion was left to the release fence of __syncthreads(), which the compiler does not turn into
+    a wait for LDS-DMA at every call site; a block whose copy was slow (typically the first tile group of a launch) multiplied by a
+    half-copied unit: whole 32-point tiles wrong in ~1 of 300 launches at 256x256x96.  The waits are written out now (wait_vmcnt)."""
+    import cnerf_amd
+    from cnerf_amd.generators import ImplicitGenerator3d
+    R, S, V, B = 128, 64, 32, 2
+    torch.manual_seed(1)
+    fvol, glob = torch.randn(B, 32, V, V, V, device=dev), torch.randn(B, 256, device=dev)
+    cam = torch.eye(4, device=dev).unsqueeze(0).repeat(B, 1, 1).contiguous()
+    cam[:, 2, 3] = -1.0
+    rng = {"u_strat": torch.rand(B, R * R, S, device=dev), "u_fine": torch.rand(B, R * R, S, device=dev)}
+    ref = None
+    for net in range(4):
+        torch.manual_seed(2)
+        gen = ImplicitGenerator3d("SHORTSIREN_FG", 256, 32, 4, 256).to(dev)
+        gen.set_device(dev)
+        gen.siren.precision = precision
+        with torch.no_grad():
+            gen.siren.final_layer.weight[3] *= 40
+        for it in range(10):
+            with torch.no_grad():
+                px, dp = gen((fvol, glob), cam, R, 49.13, 0.25, 1.95, S, True, clamp_mode="relu", nerf_noise=0.0, white_back=True, _rng=rng)
+            if ref is None:
+                ref = (px.clone(), dp.clone())
+            else:
+                assert torch.equal(px, ref[0]) and torch.equal(dp, ref[1]), (net, it, int((px != ref[0]).sum()))
