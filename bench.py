@@ -361,7 +361,9 @@ def gan_step_leg(args, dev, rank, world, dist, batch, precision, backward_precis
     from cnerf_amd.training.gan_step import PhaseTimer, synthetic_sample
     from cnerf_amd.training.miopen_db import use_shipped_db
     if not stub and not args.no_miopen_db:
-        use_shipped_db()
+        from cnerf_amd.training.latch import rank0_first
+        rank0_first(rank, f"miopen_db_{batch}_{precision}", use_shipped_db)        # one rank merges the files, ...
+        use_shipped_db(merge=False)                                                # ... every rank reads them
         # FAST find mode: a problem the database knows gets its recorded solver, one it does not falls back to immediate mode -- never
         # a minutes-long search inside the benchmark
         os.environ.setdefault("MIOPEN_FIND_MODE", "2")
@@ -384,6 +386,14 @@ def gan_step_leg(args, dev, rank, world, dist, batch, precision, backward_precis
     sync = torch.cuda.synchronize if dev.type == "cuda" else (lambda: None)
     if dev.type == "cuda":
         torch.cuda.reset_peak_memory_stats()
+    if not stub and world > 1:
+        # MIOpen compiles the solvers it selects on first use (~2 minutes for this step on a fresh node): rank 0 first, without any
+        # collective (raw modules; the others wait on a marker file), then the others find the binaries in the node's kernel cache
+        from cnerf_amd.training.latch import rank0_first
+        rank0_first(rank, f"miopen_warm_{batch}_{precision}", lambda: (tr.warm_convolutions(sample), sync()))
+        if rank != 0:
+            tr.warm_convolutions(sample)
+            sync()
     tr.step(sample)                                          # warm-up: kernel selection, DDP bucket rebuild, allocator
     tr.step(sample)
     for m in meters.values():

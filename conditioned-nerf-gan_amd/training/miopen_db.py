@@ -15,11 +15,15 @@ import shutil
 HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "miopen_db")
 
 
-def use_shipped_db(user_db=None):
-    """Call before the first convolution of the process.  Returns the user database directory (MIOPEN_USER_DB_PATH)."""
+def use_shipped_db(user_db=None, merge=True):
+    """Call before the first convolution of the process.  Returns the user database directory (MIOPEN_USER_DB_PATH).
+    merge=False only points the process at the directory: in a multi-rank job ONE rank merges the files (rank 0 first:
+    training/latch.py), the others must not write them at the same time."""
     user_db = user_db or os.environ.get("MIOPEN_USER_DB_PATH") or os.path.join(os.path.expanduser("~"), ".config", "miopen")
     os.environ["MIOPEN_USER_DB_PATH"] = user_db
     os.makedirs(user_db, exist_ok=True)
+    if not merge:
+        return user_db
     for src in glob.glob(os.path.join(HERE, "*.txt")):
         dst = os.path.join(user_db, os.path.basename(src))
         if not os.path.exists(dst):

@@ -23,6 +23,9 @@ u = torch.rand(B, R * R, S, device=dev)
 stamps = torch.zeros(64, dtype=torch.float32, device=dev)   # handed over in the (unused, non-hierarchical) cdf slot
 r = L.Rng(); r.u_strat = u.data_ptr()
 aux = L.Aux(); aux.cdf = stamps.data_ptr()
+if os.environ.get("CNERF_STORE"):        # the activation-keeping forward of the half-precision backward (fp16x3 / fp16 precisions)
+    kept = ops.resident_act16(net, [fcl], B, R, S, False, dev)
+    aux.act16[0].feat, aux.act16[0].h, aux.act16[0].c = (t.data_ptr() for t in kept[0])
 for it in range(2):
     stamps.zero_()
     vs = ops.volumes_struct([fcl])

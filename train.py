@@ -124,7 +124,8 @@ def main():
         # database instead of searching for ~7 minutes each, all at once)
         # ... and starts from the find results shipped with the repo for the default sizes (training/miopen_db.py): nothing to search then
         from cnerf_amd.training.miopen_db import use_shipped_db
-        use_shipped_db()
+        rank0_first(rank, "miopen_db", use_shipped_db)
+        use_shipped_db(merge=False)
         warm = synthetic_sample(args.batch, args.img_size, args.voxel_res, dev, torch.Generator().manual_seed(1))
         def search():
             t0 = time.perf_counter()
