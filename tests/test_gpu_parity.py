@@ -1437,3 +1437,36 @@ def test_forward_is_deterministic_over_many_launches(dev, precision):
                 ref = (px.clone(), dp.clone())
             else:
                 assert torch.equal(px, ref[0]) and torch.equal(dp, ref[1]), (net, it, int((px != ref[0]).sum()))
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fp16x3"])
+def test_config4_per_gpu_batch_is_batch_invariant(dev, precision):
+    """BASELINE config 4's per-GPU workload -- 8 images of 128x128 rays x (64 + 64) samples, 64^3 volumes, hidden 256, what bench.py
+    times -- checked by a size-independent property (the oracle takes 7 s per image): every image of the batch-8 render equals, bit
+    for bit, the same image rendered alone with its own slice of the draws.  Images are independent units of the path (one
+    feature volume, one FiLM vector, one camera each); what could couple them is exactly what a batch changes -- tile groups spanning an
+    image boundary, the per-image FiLM constants / weight copies restaged in LDS at the image switch, the XCD banding of eight images."""
+    import cnerf_amd
+    from cnerf_amd.generators import ImplicitGenerator3d
+    from cnerf_amd.generators.volumetric_rendering import sample_camera_positions, create_cam2world_matrix
+    torch.manual_seed(4)
+    np.random.seed(4)
+    B, R, S, V = 8, 128, 64, 64
+    gen = ImplicitGenerator3d("SHORTSIREN_FG", 256, 32, 4, 256).to(dev)
+    gen.set_device(dev)
+    gen.siren.precision = precision
+    with torch.no_grad():
+        gen.siren.final_layer.weight[3] *= 30
+    fvol, glob = torch.randn(B, 32, V, V, V, device=dev) * 0.5, torch.randn(B, 256, device=dev)
+    cam = create_cam2world_matrix(sample_camera_positions("cpu", "y", 0.7, 1.5, B), "y").to(dev)
+    P = R * R
+    rng = {"u_strat": torch.rand(B, P, S, device=dev), "eps_coarse": torch.randn(B, P, S, device=dev), "u_fine": torch.rand(B, P, S, device=dev),
+           "eps_final": torch.randn(B, P, 2 * S, device=dev)}
+    meta = dict(clamp_mode="softplus", nerf_noise=0.5, white_back=True)
+    with torch.no_grad():
+        px, dp = gen((fvol, glob), cam, R, 49.13, 0.25, 1.95, S, True, _rng=rng, **meta)
+        assert torch.isfinite(px).all() and torch.isfinite(dp).all()
+        for i in (0, 3, 7):
+            one = {k: v[i:i + 1].contiguous() for k, v in rng.items()}
+            pi, di = gen((fvol[i:i + 1].contiguous(), glob[i:i + 1].contiguous()), cam[i:i + 1].contiguous(), R, 49.13, 0.25, 1.95, S, True, _rng=one, **meta)
+            assert torch.equal(pi[0], px[i]) and torch.equal(di[0], dp[i]), i
