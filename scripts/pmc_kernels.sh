@@ -14,4 +14,4 @@ for C in "GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_INSTS_MFMA SQ_VALU_
     timeout -k 10 300 rocprofv3 --kernel-trace --pmc $C -d gpurun_out/pmck_${W}_$i -o x --output-format csv -- $CMD > gpurun_out/pmck_${W}_$i.log 2>&1 || echo "set $i $W failed"
   done
 done
-python3 scripts/pmc_table.py > gpurun_out/r02_kernel_counters.md
+python3 scripts/pmc_table.py > gpurun_out/r3/kernel_counters_table.md
