@@ -258,7 +258,9 @@ struct Epi16 {
     const float* fr;          // LDS: freq of the slab (FiLM) or null (plain sine)
     _Float16* gdst;           // g16 row of the lane's point, channel tile 0 of the slab (+ 4 h)
     float vmax;               // running max |gp * T| of the point (this lane's channels)
-    float gmax;               // running max |ga * S| (DRY: the sampled maximum; chain run: did anything exceed fp16's range?)
+    float gmax;               // DRY: running max |ga * S|
+    unsigned long long sat;   // chain run: lanes that clamped a stored gradient to fp16's range (a wave-uniform mask: lives in scalar registers --
+                              // a per-lane running maximum here cost 70 spilled dwords in this kernel)
     float s4[4];              // the stored quad being assembled
     float gp_even;            // the operand pair being assembled
     bool live;
@@ -283,8 +285,9 @@ __device__ __forceinline__ void epi16_element(const f32x16& acc, const f16x4* co
     const float f = st.fr ? st.fr[32 * t + 8 * gq + 4 * h + e] : 1.0f;
     const float gt = (ac * f) * st.UT;                                       // gp * T
     st.vmax = fmaxf(st.vmax, fabsf(gt));
-    st.gmax = fmaxf(st.gmax, fabsf(gs));
-    if (!DRY) {
+    if (DRY) st.gmax = fmaxf(st.gmax, fabsf(gs));
+    else {
+        st.sat |= __ballot(fabsf(gs) > 65504.0f);
         st.s4[e] = __builtin_amdgcn_fmed3f(gs, -65504.0f, 65504.0f);
         if (e == 3 && st.live)
             *reinterpret_cast<u32x2_*>(st.gdst + t * 1024 + 8 * gq) = u32x2_{pk_f16(st.s4[0], st.s4[1]), pk_f16(st.s4[2], st.s4[3])};
@@ -455,6 +458,7 @@ __global__ __launch_bounds__(256) void chain16_kernel(Chain16Args A) {
             st.gdst = A.g16 + (size_t)m * slab16 + row16 + 4 * h;
             st.vmax = 0.0f;
             st.gmax = 0.0f;
+            st.sat = 0ull;
             st.kskip = 0.0f;
             return T;
         };
@@ -472,7 +476,7 @@ __global__ __launch_bounds__(256) void chain16_kernel(Chain16Args A) {
 #pragma unroll
                 for (int d = 32; d >= 1; d >>= 1) gm = fmaxf(gm, __shfl_xor(gm, d, WAVE));
                 if (lane == 0) atomicMax(A.gmax + m, __float_as_uint(gm));
-            } else if (A.sat && __any(st.live && st.gmax > 65504.0f)) {        // the scale came from a SAMPLED maximum: say so when it was too small
+            } else if (A.sat && st.live && st.sat != 0ull) {                   // the scale came from a SAMPLED maximum: say so when it was too small
                 if (lane == 0) atomicAdd(A.sat, 1u);
             }
             const float v = fmaxf(st.vmax, __shfl_xor(st.vmax, 32, WAVE));     // the two lane halves of a point
