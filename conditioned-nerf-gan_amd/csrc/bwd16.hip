@@ -259,8 +259,6 @@ struct Epi16 {
     _Float16* gdst;           // g16 row of the lane's point, channel tile 0 of the slab (+ 4 h)
     float vmax;               // running max |gp * T| of the point (this lane's channels)
     float gmax;               // DRY: running max |ga * S|
-    unsigned long long sat;   // chain run: lanes that clamped a stored gradient to fp16's range (a wave-uniform mask: lives in scalar registers --
-                              // a per-lane running maximum here cost 70 spilled dwords in this kernel)
     float s4[4];              // the stored quad being assembled
     float gp_even;            // the operand pair being assembled
     bool live;
@@ -287,7 +285,6 @@ __device__ __forceinline__ void epi16_element(const f32x16& acc, const f16x4* co
     st.vmax = fmaxf(st.vmax, fabsf(gt));
     if (DRY) st.gmax = fmaxf(st.gmax, fabsf(gs));
     else {
-        st.sat |= __ballot(fabsf(gs) > 65504.0f);
         st.s4[e] = __builtin_amdgcn_fmed3f(gs, -65504.0f, 65504.0f);
         if (e == 3 && st.live)
             *reinterpret_cast<u32x2_*>(st.gdst + t * 1024 + 8 * gq) = u32x2_{pk_f16(st.s4[0], st.s4[1]), pk_f16(st.s4[2], st.s4[3])};
@@ -309,7 +306,8 @@ __global__ __launch_bounds__(256) void chain16_kernel(Chain16Args A) {
     f16x8* lds_head = lds_units + 3 * UNIT_FR;                                              // NT * 64 fragments
     float* lds_freq = reinterpret_cast<float*>(lds_head + NT * 64);                        // film_stride floats (image of the block)
     float* lds_fmax = lds_freq + (a.film_stride > 0 ? a.film_stride : 4);                  // per slab: max |freq| of the image (1: sine)
-    float* s_g = lds_fmax + C16_MAX_SLABS;                                              // [4][32][33] scatter transpose
+    float* lds_fmin = lds_fmax + C16_MAX_SLABS;                                            // per slab: min |freq| of the image (1: sine)
+    float* s_g = lds_fmin + C16_MAX_SLABS;                                              // [4][32][33] scatter transpose
     int* s_base = reinterpret_cast<int*>(s_g + 4 * 32 * 33);                               // [4][32][8]
     float* s_w = reinterpret_cast<float*>(s_base + 4 * 32 * 8);                            // [4][32][8]
 
@@ -368,7 +366,7 @@ __global__ __launch_bounds__(256) void chain16_kernel(Chain16Args A) {
     const float S_go = A.scales[2 * A.nslab], winv_head = A.winv[A.nslab];
     const float* anorm = A.winv + A.nslab + 1;                  // ||W_m||_1 per slab, then the head's
     if (!a.freq) {
-        for (int i = threadIdx.x; i < C16_MAX_SLABS; i += 256) lds_fmax[i] = 1.0f;
+        for (int i = threadIdx.x; i < 2 * C16_MAX_SLABS; i += 256) lds_fmax[i] = 1.0f;      // (lds_fmin follows lds_fmax)
         __syncthreads();
     }
 
@@ -386,16 +384,28 @@ __global__ __launch_bounds__(256) void chain16_kernel(Chain16Args A) {
         if (b != staged_b && a.freq) {                                                     // block-uniform: FiLM vectors of the image
             __syncthreads();
             for (int i = threadIdx.x; i < a.film_stride; i += 256) lds_freq[i] = a.freq[(size_t)b * a.film_stride + i];
-            for (int i = threadIdx.x; i < C16_MAX_SLABS; i += 256) lds_fmax[i] = 1.0f;
+            for (int i = threadIdx.x; i < C16_MAX_SLABS; i += 256) {
+                lds_fmax[i] = 1.0f;
+                lds_fmin[i] = (i < A.nslab && A.slab_kind[i] == C16_FILM) ? __uint_as_float(0x7f7fffffu) : 1.0f;
+            }
             __syncthreads();
             int fi = 0;
             for (int m = 0; m < A.nslab; ++m) {
                 if (A.slab_kind[m] != C16_FILM) continue;
-                float v = 0.0f;
-                for (int i = threadIdx.x; i < NT * 32; i += 256) v = fmaxf(v, fabsf(lds_freq[fi * NT * 32 + i]));
+                float v = 0.0f, vmin = 3e38f;
+                for (int i = threadIdx.x; i < NT * 32; i += 256) {
+                    v = fmaxf(v, fabsf(lds_freq[fi * NT * 32 + i]));
+                    vmin = fminf(vmin, fabsf(lds_freq[fi * NT * 32 + i]));
+                }
 #pragma unroll
-                for (int d = 32; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d, WAVE));
-                if (lane == 0) atomicMax(reinterpret_cast<unsigned int*>(lds_fmax + m), __float_as_uint(v));   // (>= 1 already there: FiLM freq ~ 30)
+                for (int d = 32; d >= 1; d >>= 1) {
+                    v = fmaxf(v, __shfl_xor(v, d, WAVE));
+                    vmin = fminf(vmin, __shfl_xor(vmin, d, WAVE));
+                }
+                if (lane == 0) {
+                    atomicMax(reinterpret_cast<unsigned int*>(lds_fmax + m), __float_as_uint(v));   // (>= 1 already there: FiLM freq ~ 30)
+                    atomicMin(reinterpret_cast<unsigned int*>(lds_fmin + m), __float_as_uint(fmaxf(vmin, 1e-30f)));
+                }
                 ++fi;
             }
             staged_b = b;
@@ -458,7 +468,6 @@ __global__ __launch_bounds__(256) void chain16_kernel(Chain16Args A) {
             st.gdst = A.g16 + (size_t)m * slab16 + row16 + 4 * h;
             st.vmax = 0.0f;
             st.gmax = 0.0f;
-            st.sat = 0ull;
             st.kskip = 0.0f;
             return T;
         };
@@ -476,7 +485,12 @@ __global__ __launch_bounds__(256) void chain16_kernel(Chain16Args A) {
 #pragma unroll
                 for (int d = 32; d >= 1; d >>= 1) gm = fmaxf(gm, __shfl_xor(gm, d, WAVE));
                 if (lane == 0) atomicMax(A.gmax + m, __float_as_uint(gm));
-            } else if (A.sat && st.live && st.sat != 0ull) {                   // the scale came from a SAMPLED maximum: say so when it was too small
+            } else if (A.sat && st.live && __any(st.vmax * (A.scales[2 * m] / (T * lds_fmin[m])) > 65504.0f)) {
+                // The stored scale came from a SAMPLED maximum: say so when it was too small -- at no cost per element (a per-lane
+                // running maximum of the stored values spilled 70 dwords in this kernel; a per-element lane mask stalled on the vector-
+                // compare -> scalar-or hazard: 123 -> 142 ms per step on the residual network).  stored = operand * S_m / (T freq), and
+                // the operand's running maximum is tracked anyway (vmax): with the image's smallest |freq| of the slab this bounds the
+                // stored values from above -- the count may include tiles that came within max|freq| / min|freq| of the clamp.
                 if (lane == 0) atomicAdd(A.sat, 1u);
             }
             const float v = fmaxf(st.vmax, __shfl_xor(st.vmax, 32, WAVE));     // the two lane halves of a point
@@ -770,7 +784,7 @@ static hipError_t launch_chain16_nt(const FieldArgs& f, const Chain16Launch& c, 
     if (hipGetDevice(&dev) != hipSuccess) dev = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
     const size_t lds_bytes = (size_t)3 * (2 * 2 * NT * 64) * 16 + (size_t)NT * 64 * 16 + (size_t)(f.film_stride > 0 ? f.film_stride : 4) * 4 +
-                             (size_t)C16_MAX_SLABS * 4 + (size_t)4 * 32 * 33 * 4 + (size_t)2 * 4 * 32 * 8 * 4;
+                             (size_t)2 * C16_MAX_SLABS * 4 + (size_t)4 * 32 * 33 * 4 + (size_t)2 * 4 * 32 * 8 * 4;
     if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
     if (hipError_t e = hipFuncSetAttribute((const void*)chain16_kernel<NT, DRY, HAS_RES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)) return e;
     const long long want = (f.total_tiles / f.tiles_per_image) * ((f.tiles_per_image + 3) / 4);
