@@ -257,8 +257,9 @@ struct Epi16 {
     float US, UT;             // accumulator -> stored scale (U * S_m) and -> operand scale (U * T)
     const float* fr;          // LDS: freq of the slab (FiLM) or null (plain sine)
     _Float16* gdst;           // g16 row of the lane's point, channel tile 0 of the slab (+ 4 h)
-    float vmax;               // running max |gp * T| of the point (this lane's channels)
-    float gmax;               // DRY: running max |ga * S|
+    float vmax;               // running max |acc * cos| of the point (this lane's channels; accumulator units): ONE tracked maximum serves the
+                              // dry run's sampled maximum and the chain run's clamp report (x US = the stored value before its clamp, exactly) and,
+                              // times the slab's max |freq|, the bound on the next slab's operands
     float s4[4];              // the stored quad being assembled
     float gp_even;            // the operand pair being assembled
     bool live;
@@ -282,9 +283,8 @@ __device__ __forceinline__ void epi16_element(const f32x16& acc, const f16x4* co
     const float gs = ac * st.US;                                             // ga * S_m
     const float f = st.fr ? st.fr[32 * t + 8 * gq + 4 * h + e] : 1.0f;
     const float gt = (ac * f) * st.UT;                                       // gp * T
-    st.vmax = fmaxf(st.vmax, fabsf(gt));
-    if (DRY) st.gmax = fmaxf(st.gmax, fabsf(gs));
-    else {
+    st.vmax = fmaxf(st.vmax, fabsf(ac));
+    if (!DRY) {
         st.s4[e] = __builtin_amdgcn_fmed3f(gs, -65504.0f, 65504.0f);
         if (e == 3 && st.live)
             *reinterpret_cast<u32x2_*>(st.gdst + t * 1024 + 8 * gq) = u32x2_{pk_f16(st.s4[0], st.s4[1]), pk_f16(st.s4[2], st.s4[3])};
@@ -300,14 +300,17 @@ __global__ __launch_bounds__(256) void chain16_kernel(Chain16Args A) {
     constexpr int KCH = 2 * NT;                         // k-chunks of 16 per matrix row tile
     constexpr int UNIT_FR = 2 * KCH * 64;               // f16x8 fragments per weight unit (two output tiles)
     constexpr int PW = (2 * KCH) / 4;                   // 1-KiB pieces each wave copies per unit
-    constexpr int CD = NT;                              // cos prefetch distance, in output tiles: a whole slab ahead
+    // cos prefetch distance, in output tiles.  A quarter of a slab (2 tiles at H = 256, ~8 us of MFMAs: several HBM round trips) instead
+    // of round 2's whole slab: 48 fewer registers for the ring -- with one tracked maximum (Epi16::vmax) the three H = 256 instantiations
+    // spill 20 / 8 / 20 bytes (chain / dry run / residual) where a whole slab ahead spilled 20 / 308 / 120 and round 2's code 20 / 316 / 132;
+    // measured equal in time (78.5-79.6 ms per step whichever distance), kept for the margin to the 512-register limit
+    constexpr int CD = NT >= 8 ? NT / 4 : (NT >= 2 ? 2 : 1);
     constexpr int EPC = 16 / KCH > 0 ? 16 / KCH : 1;    // epilogue elements per k-chunk (KCH = 16: one)
     f16x8* lds_units = reinterpret_cast<f16x8*>(smem_c);                                   // 3 slots
     f16x8* lds_head = lds_units + 3 * UNIT_FR;                                              // NT * 64 fragments
     float* lds_freq = reinterpret_cast<float*>(lds_head + NT * 64);                        // film_stride floats (image of the block)
     float* lds_fmax = lds_freq + (a.film_stride > 0 ? a.film_stride : 4);                  // per slab: max |freq| of the image (1: sine)
-    float* lds_fmin = lds_fmax + C16_MAX_SLABS;                                            // per slab: min |freq| of the image (1: sine)
-    float* s_g = lds_fmin + C16_MAX_SLABS;                                              // [4][32][33] scatter transpose
+    float* s_g = lds_fmax + C16_MAX_SLABS;                                              // [4][32][33] scatter transpose
     int* s_base = reinterpret_cast<int*>(s_g + 4 * 32 * 33);                               // [4][32][8]
     float* s_w = reinterpret_cast<float*>(s_base + 4 * 32 * 8);                            // [4][32][8]
 
@@ -366,7 +369,7 @@ __global__ __launch_bounds__(256) void chain16_kernel(Chain16Args A) {
     const float S_go = A.scales[2 * A.nslab], winv_head = A.winv[A.nslab];
     const float* anorm = A.winv + A.nslab + 1;                  // ||W_m||_1 per slab, then the head's
     if (!a.freq) {
-        for (int i = threadIdx.x; i < 2 * C16_MAX_SLABS; i += 256) lds_fmax[i] = 1.0f;      // (lds_fmin follows lds_fmax)
+        for (int i = threadIdx.x; i < C16_MAX_SLABS; i += 256) lds_fmax[i] = 1.0f;
         __syncthreads();
     }
 
@@ -384,28 +387,16 @@ __global__ __launch_bounds__(256) void chain16_kernel(Chain16Args A) {
         if (b != staged_b && a.freq) {                                                     // block-uniform: FiLM vectors of the image
             __syncthreads();
             for (int i = threadIdx.x; i < a.film_stride; i += 256) lds_freq[i] = a.freq[(size_t)b * a.film_stride + i];
-            for (int i = threadIdx.x; i < C16_MAX_SLABS; i += 256) {
-                lds_fmax[i] = 1.0f;
-                lds_fmin[i] = (i < A.nslab && A.slab_kind[i] == C16_FILM) ? __uint_as_float(0x7f7fffffu) : 1.0f;
-            }
+            for (int i = threadIdx.x; i < C16_MAX_SLABS; i += 256) lds_fmax[i] = 1.0f;
             __syncthreads();
             int fi = 0;
             for (int m = 0; m < A.nslab; ++m) {
                 if (A.slab_kind[m] != C16_FILM) continue;
-                float v = 0.0f, vmin = 3e38f;
-                for (int i = threadIdx.x; i < NT * 32; i += 256) {
-                    v = fmaxf(v, fabsf(lds_freq[fi * NT * 32 + i]));
-                    vmin = fminf(vmin, fabsf(lds_freq[fi * NT * 32 + i]));
-                }
+                float v = 0.0f;
+                for (int i = threadIdx.x; i < NT * 32; i += 256) v = fmaxf(v, fabsf(lds_freq[fi * NT * 32 + i]));
 #pragma unroll
-                for (int d = 32; d >= 1; d >>= 1) {
-                    v = fmaxf(v, __shfl_xor(v, d, WAVE));
-                    vmin = fminf(vmin, __shfl_xor(vmin, d, WAVE));
-                }
-                if (lane == 0) {
-                    atomicMax(reinterpret_cast<unsigned int*>(lds_fmax + m), __float_as_uint(v));   // (>= 1 already there: FiLM freq ~ 30)
-                    atomicMin(reinterpret_cast<unsigned int*>(lds_fmin + m), __float_as_uint(fmaxf(vmin, 1e-30f)));
-                }
+                for (int d = 32; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d, WAVE));
+                if (lane == 0) atomicMax(reinterpret_cast<unsigned int*>(lds_fmax + m), __float_as_uint(v));   // (>= 1 already there: FiLM freq ~ 30)
                 ++fi;
             }
             staged_b = b;
@@ -467,7 +458,6 @@ __global__ __launch_bounds__(256) void chain16_kernel(Chain16Args A) {
             st.UT = U * T;
             st.gdst = A.g16 + (size_t)m * slab16 + row16 + 4 * h;
             st.vmax = 0.0f;
-            st.gmax = 0.0f;
             st.kskip = 0.0f;
             return T;
         };
@@ -479,22 +469,22 @@ __global__ __launch_bounds__(256) void chain16_kernel(Chain16Args A) {
                 skip_max = gpmax_m;
             }
         };
-        auto end_slab = [&](int m, float T) -> float {                             // returns the point's max |gp| in true units
+        auto end_slab = [&](int m, float T) -> float {                             // returns a bound on the point's max |gp| in true units
+            (void)T;
+            const float vm = fmaxf(st.vmax, __shfl_xor(st.vmax, 32, WAVE)) * st.US;   // the two lane halves of a point: max |ga| * S_m
             if (DRY) {
-                float gm = st.gmax / A.scales[2 * m];
+                float gm = vm / A.scales[2 * m];
 #pragma unroll
-                for (int d = 32; d >= 1; d >>= 1) gm = fmaxf(gm, __shfl_xor(gm, d, WAVE));
+                for (int d = 16; d >= 1; d >>= 1) gm = fmaxf(gm, __shfl_xor(gm, d, WAVE));
                 if (lane == 0) atomicMax(A.gmax + m, __float_as_uint(gm));
-            } else if (A.sat && st.live && __any(st.vmax * (A.scales[2 * m] / (T * lds_fmin[m])) > 65504.0f)) {
-                // The stored scale came from a SAMPLED maximum: say so when it was too small -- at no cost per element (a per-lane
-                // running maximum of the stored values spilled 70 dwords in this kernel; a per-element lane mask stalled on the vector-
-                // compare -> scalar-or hazard: 123 -> 142 ms per step on the residual network).  stored = operand * S_m / (T freq), and
-                // the operand's running maximum is tracked anyway (vmax): with the image's smallest |freq| of the slab this bounds the
-                // stored values from above -- the count may include tiles that came within max|freq| / min|freq| of the clamp.
+            } else if (A.sat && st.live && __any(vm > 65504.0f)) {
+                // The stored scale came from a SAMPLED maximum: say so when it was too small -- exactly, and at no cost per element: the
+                // maximum tracked for the operand bound IS the stored quantity before its clamp.  (A second per-lane maximum spilled 70
+                // dwords in this kernel; a per-element lane mask stalled on the vector-compare -> scalar-or hazard, 123 -> 142 ms per
+                // step on the residual network.)
                 if (lane == 0) atomicAdd(A.sat, 1u);
             }
-            const float v = fmaxf(st.vmax, __shfl_xor(st.vmax, 32, WAVE));     // the two lane halves of a point
-            return v / T;
+            return vm / A.scales[2 * m] * lds_fmax[m];                          // |gp| = |ga| |freq| <= max |ga| * max |freq| of the slab
         };
         // linear (slab, tile) position -> the cos prefetch CD tiles ahead
         auto prefetch_after = [&](int m, int t) {
@@ -784,7 +774,7 @@ static hipError_t launch_chain16_nt(const FieldArgs& f, const Chain16Launch& c, 
     if (hipGetDevice(&dev) != hipSuccess) dev = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
     const size_t lds_bytes = (size_t)3 * (2 * 2 * NT * 64) * 16 + (size_t)NT * 64 * 16 + (size_t)(f.film_stride > 0 ? f.film_stride : 4) * 4 +
-                             (size_t)2 * C16_MAX_SLABS * 4 + (size_t)4 * 32 * 33 * 4 + (size_t)2 * 4 * 32 * 8 * 4;
+                             (size_t)C16_MAX_SLABS * 4 + (size_t)4 * 32 * 33 * 4 + (size_t)2 * 4 * 32 * 8 * 4;
     if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
     if (hipError_t e = hipFuncSetAttribute((const void*)chain16_kernel<NT, DRY, HAS_RES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)) return e;
     const long long want = (f.total_tiles / f.tiles_per_image) * ((f.tiles_per_image + 3) / 4);
