@@ -263,6 +263,11 @@ int cnerf_workspace_bytes(const cnerf_cfg* cfg, size_t* packed, size_t* fvol_cl,
         const size_t layer_floats = (NT * pl.n_in + (mats - 1) * NT * NT) * 1024;
         *fwd_ws = 2 * align256(N * 4 * sizeof(float)) + 2 * align256(N * sizeof(float)) + align256((size_t)4 * cfg->B * mats * cfg->H * sizeof(float)) +
                   align256((size_t)cfg->B * layer_floats * sizeof(float));
+        // fp16 precisions: the per-image copies of the whole packed weight stream (rows scaled by the image's FiLM frequencies), their
+        // constants K S' / 1 / S' and the row multipliers (field_h3.hip, "weight folding per image") instead of the fp32 ones
+        if (cfg->precision != CNERF_PREC_FP32 && cfg->layer_kind[0] != CNERF_LAYER_PFILM)
+            *fwd_ws = 2 * align256(N * 4 * sizeof(float)) + 2 * align256(N * sizeof(float)) + align256((size_t)cfg->B * pl.weight_floats * sizeof(float)) +
+                      align256((size_t)cfg->B * mats * (cfg->H + 1) * sizeof(float)) + align256((size_t)cfg->B * mats * cfg->H * sizeof(float));
     }
     return CNERF_OK;
 }
@@ -503,6 +508,23 @@ int cnerf_render_forward(const cnerf_cfg* cfg, const cnerf_volumes* vols, const 
             fa.packed_img = packed_img;
             fa.packed_img_stride = layer_floats;
         }
+    }
+    // the fp16 precisions: the same folding on two-part fp16 weights -- per-image copies of the packed stream, the accumulators start
+    // from (freq bias + phase) / 2 pi, the epilogue is one multiply, the range reduction and v_sin (field_h3.hip)
+    if (cfg->precision != CNERF_PREC_FP32 && cfg->layer_kind[0] != CNERF_LAYER_PFILM) {
+        char* w16 = (char*)fold;                  // (the fp32 regions are not used in these precisions: same place in the workspace)
+        void* img = w16;
+        w16 += align256((size_t)cfg->B * pl.weight_floats * sizeof(float));
+        float* fold16 = (float*)w16;
+        w16 += align256((size_t)cfg->B * fa.n_mats * (cfg->H + 1) * sizeof(float));
+        float* rowf = (float*)w16;
+        const long long img_elems = (long long)pl.weight_floats * 2;            // fp16 elements of the packed weight stream
+        if (hipError_t e = (cfg->precision == CNERF_PREC_FP16 ? launch_fold_h1 : launch_fold_h3)(fa, cfg->B, cfg->H, img, fold16, rowf, img_elems, stream))
+            return hip_fail(e, "fold16");
+        fa.packed_img = (const float*)img;
+        fa.packed_img_stride = img_elems / 8;     // in f16x8 fragments
+        fa.fold = fold16;
+        fa.fold_images = cfg->B;
     }
     // 1. coarse pass
     fa.mode = FIELD_MODE_COARSE;

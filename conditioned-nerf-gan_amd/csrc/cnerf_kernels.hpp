@@ -80,6 +80,9 @@ hipError_t launch_scale_packed(const FieldArgs& a, int B, int H, const float* mh
 hipError_t launch_field(const FieldArgs& a, int H, hipStream_t stream);
 hipError_t launch_field_h3(const FieldArgs& a, int H, hipStream_t stream);
 hipError_t launch_field_h1(const FieldArgs& a, int H, hipStream_t stream);      // field_h3.hip compiled with CNERF_H3_PARTS=1
+// per-image weight folding of the fp16 kernels (field_h3.hip): img (B, img_elems fp16), fold (B, n_mats * (H + 1)), rowf (B, n_mats, H) scratch
+hipError_t launch_fold_h3(const FieldArgs& a, int B, int H, void* img, float* fold, float* rowf, long long img_elems, hipStream_t stream);
+hipError_t launch_fold_h1(const FieldArgs& a, int B, int H, void* img, float* fold, float* rowf, long long img_elems, hipStream_t stream);
 hipError_t launch_pack_h1(const float* w, int n_out, int K_real, int OT, bool k_outer, void* dst, float* inv_scale_slot, float* wmax_slot,
                           hipStream_t stream);
 hipError_t launch_pack_h3(const float* w, int n_out, int K_real, int OT, bool k_outer, void* dst, float* inv_scale_slot, float* wmax_slot,

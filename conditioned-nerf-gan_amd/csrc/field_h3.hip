@@ -44,10 +44,12 @@
 #define H3_NS h1
 #define H3_LAUNCH_FIELD launch_field_h1
 #define H3_LAUNCH_PACK launch_pack_h1
+#define H3_LAUNCH_FOLD launch_fold_h1
 #else
 #define H3_NS h3
 #define H3_LAUNCH_FIELD launch_field_h3
 #define H3_LAUNCH_PACK launch_pack_h3
+#define H3_LAUNCH_FOLD launch_fold_h3
 #endif
 
 namespace cnerf {
@@ -153,6 +155,124 @@ static hipError_t pack_impl(const float* w, int n_out, int K_real, int OT, bool 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Weight folding per image (cnerf_render_forward; the WF instantiations of the kernel below).  As in field_kernel.hip: a scale of
+// output rows is a scale of weight rows, so per call and image the packed matrices are re-split with row i scaled by
+//     r_b[i] = freq_b[i] / 2 pi   (FiLM)        1 / 2 pi   (plain sine, both matrices of a residual block)
+// and the accumulators start from K_b[i] = (freq_b[i] bias[i] + phase_b[i]) / 2 pi: the accumulator is the argument in revolutions.
+// The per-matrix power-of-two scale S moves by the power of two above max_i r_b[i] so that both fp16 parts stay in range:
+// S' = S 2^-e.  fold16_prepare_kernel: per (image, matrix) the row multipliers r 2^-e, 1 / S', and K S' (in double);
+// scale16_kernel: every fragment element = (hi + lo) * multiplier, split again (22 significant bits in, 22 out).  Two launches
+// per call for both field passes; 0.8 MB per image (one image per XCD's L2 under the tile banding).
+// ---------------------------------------------------------------------------------------------------------------
+struct Fold16Args {
+    const _Float16* packed;     // the shared packed weight stream (pack_h3_kernel), all matrices then the head
+    const float* bias;          // behind it: biases (n_mats x H), head bias (4), 1 / S per matrix and the head's
+    const float* freq;          // (B, film_stride) or null
+    const float* phase;
+    _Float16* img;              // (B, img_elems): the per-image copies
+    float* fold;                // (B, n_mats * (H + 1)): K S' per matrix and channel, then 1 / S' per matrix
+    float* rowf;                // (B, n_mats, H) scratch: row multipliers r 2^-e
+    long long img_elems;
+    int B, H, NT, n_mats, L, film_stride;
+    int layer_kind[CNERF_MAX_LAYERS];
+    int pair_begin[2 * CNERF_MAX_LAYERS + 2];   // first fragment pair of every matrix, then of the head, then the end
+};
+
+__global__ __launch_bounds__(256) void fold16_prepare_kernel(Fold16Args a) {
+    __shared__ float s_max[4];
+    const int b = blockIdx.x / a.n_mats, m = blockIdx.x - b * a.n_mats, i = threadIdx.x;
+    int film = -1, mats = 0, films = 0;                 // FiLM index of matrix m (-1: plain sine / residual half)
+    for (int l = 0; l < a.L; ++l) {
+        const int kind = a.layer_kind[l];
+        if (kind == CNERF_LAYER_FILM && mats == m) film = films;
+        films += kind == CNERF_LAYER_FILM;
+        mats += kind == CNERF_LAYER_RES ? 2 : 1;
+    }
+    const bool on = i < a.H;
+    const double fr = (on && film >= 0) ? (double)a.freq[(size_t)b * a.film_stride + (size_t)film * a.H + i] : 1.0;
+    const double ph = (on && film >= 0) ? (double)a.phase[(size_t)b * a.film_stride + (size_t)film * a.H + i] : 0.0;
+    const double r = fr * 0.15915494309189533577;
+    float rm = on ? fabsf((float)r) : 0.0f;
+#pragma unroll
+    for (int d = WAVE / 2; d >= 1; d >>= 1) rm = fmaxf(rm, __shfl_xor(rm, d, WAVE));
+    if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = rm;
+    __syncthreads();
+    rm = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
+    int e = 0;
+    if (rm > 1e-30f && rm < 3e38f) {
+        const float mant = frexpf(rm, &e);              // rm = mant 2^e, mant in [0.5, 1): rm <= 2^e
+        if (mant == 0.5f) e -= 1;                       // an exact power of two
+    }
+    e = e > 60 ? 60 : (e < -60 ? -60 : e);
+    const double shift = ldexp(1.0, -e);                // r 2^-e <= 1 for every row
+    const double inv_s = (double)a.bias[(size_t)a.n_mats * a.H + 4 + m];
+    if (on) {
+        a.rowf[((size_t)b * a.n_mats + m) * a.H + i] = (float)(r * shift);
+        a.fold[(size_t)b * a.n_mats * (a.H + 1) + (size_t)m * a.H + i] =
+            (float)((fr * (double)a.bias[(size_t)m * a.H + i] + ph) * 0.15915494309189533577 * shift / inv_s);
+    }
+    if (i == 0) a.fold[(size_t)b * a.n_mats * (a.H + 1) + (size_t)a.n_mats * a.H + m] = (float)(inv_s / shift);
+}
+
+__global__ void scale16_kernel(Fold16Args a) {
+    const long long per_image = (long long)a.pair_begin[a.n_mats + 1] * 512;          // (pair, lane, j) triples per image
+    const long long total = per_image * a.B;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int b = (int)(idx / per_image);
+        const long long q = idx - (long long)b * per_image;
+        const int j = (int)(q & 7), lane = (int)((q >> 3) & 63), pair = (int)(q >> 9);
+        int m = 0;
+        while (m < a.n_mats && pair >= a.pair_begin[m + 1]) ++m;
+        const size_t base = ((size_t)pair * PARTS) * 512 + (size_t)lane * 8 + j;
+        float v = (float)a.packed[base];
+        if (PARTS == 2) v += (float)a.packed[base + 512];
+        if (m < a.n_mats) {                              // (the head's unit is copied as it is)
+            const int pl = pair - a.pair_begin[m];
+            const int t = m == 0 ? (pl >> 1) % a.NT : pl / (2 * a.NT);
+            v *= a.rowf[((size_t)b * a.n_mats + m) * a.H + 32 * t + (lane & 31)];
+        }
+        _Float16* dst = a.img + (size_t)b * a.img_elems + base;
+        const _Float16 a0 = (_Float16)v;
+        dst[0] = a0;
+        if (PARTS == 2) dst[512] = (_Float16)(v - (float)a0);
+    }
+}
+
+static hipError_t fold_impl(const FieldArgs& f, int B, int H, void* img, float* fold, float* rowf, long long img_elems, hipStream_t stream) {
+    Fold16Args a;
+    a.packed = reinterpret_cast<const _Float16*>(f.packed);
+    a.bias = f.bias;
+    a.freq = f.freq;
+    a.phase = f.phase;
+    a.img = reinterpret_cast<_Float16*>(img);
+    a.fold = fold;
+    a.rowf = rowf;
+    a.img_elems = img_elems;
+    a.B = B;
+    a.H = H;
+    a.NT = H / 32;
+    a.n_mats = f.n_mats;
+    a.L = f.L;
+    a.film_stride = f.film_stride;
+    for (int l = 0; l < CNERF_MAX_LAYERS; ++l) a.layer_kind[l] = l < f.L ? f.layer_kind[l] : 0;
+    int pairs = 0;
+    for (int m = 0; m < f.n_mats; ++m) {
+        a.pair_begin[m] = pairs;
+        pairs += a.NT * 2 * (m == 0 ? f.n_in : a.NT);
+    }
+    a.pair_begin[f.n_mats] = pairs;                      // head: one 32-row tile
+    pairs += 2 * a.NT;
+    a.pair_begin[f.n_mats + 1] = pairs;
+    if ((long long)pairs * PARTS * 512 != img_elems) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(fold16_prepare_kernel, dim3((unsigned)(B * f.n_mats)), dim3(256), 0, stream, a);
+    const long long total = (long long)pairs * 512 * B;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(scale16_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // epilogue: bias, FiLM, sine, split
 // ---------------------------------------------------------------------------------------------------------------
 // bias / freq / phase of channels (r, r+1) of output tile t, lane half h, from LDS.  Issued one step ahead of their use:
@@ -212,12 +332,26 @@ __device__ __forceinline__ float half_hi(uint32_t u) { return (float)__builtin_b
 // element and everything that needs both (stores, split) -- the two halves of the balanced epilogue, one k-chunk apart, so
 // that every chunk of the MFMA loop carries about the same number of vector instructions (an un-split pair every second
 // chunk puts ~9 vector slots into each of three MFMA gaps and none into the next three).
-template <int STORE, bool RESID, int PHASE = 0>
+// WF (weight-folded, cnerf_render_forward; scale16_kernel below): the unit came from the IMAGE's copy of the weights, rows scaled by
+// freq / 2 pi (FiLM) or 1 / 2 pi (plain sine, both matrices of a residual block), and the accumulator started from (freq bias + phase) / 2 pi
+// in the same units -- acc * inv_s IS the argument in revolutions: one multiply, the range reduction (WF = 1: v_fract, FiLM networks;
+// WF = 2: u - rint(u), exact, networks of plain sine layers whose few-radian arguments feel fract's half ulp: as in field_kernel.hip),
+// v_sin.  No per-channel constants in the epilogue at all; a residual block's second matrix adds its input, x / 2 pi, first.
+template <int STORE, bool RESID, int PHASE = 0, int WF = 0>
 __device__ __forceinline__ void film_split_pair(const f32x16& acc, float inv_s, const FilmPair& f, int t, int h, int r, Split2* out2,
                                                 ActStore& st) {
     float a0 = 0.0f, a1 = 0.0f;
-    constexpr bool FOLD = !RESID;
-    if (FOLD) {             // a0, a1 = the argument in revolutions, reduced to about [-1/2, 1/2] + K
+    constexpr bool FOLD = !RESID || WF != 0;
+    if (WF) {
+        float u0 = acc[r] * inv_s, u1 = acc[r + 1] * inv_s;
+        if (RESID) {
+            const uint32_t xh = out2[r >> 3].p[0][(r & 7) >> 1], xl = PARTS == 2 ? out2[r >> 3].p[PARTS - 1][(r & 7) >> 1] : 0u;
+            u0 = __builtin_fmaf(half_lo(xh) + half_lo(xl), 0.15915494309189535f, u0);
+            u1 = __builtin_fmaf(half_hi(xh) + half_hi(xl), 0.15915494309189535f, u1);
+        }
+        a0 = WF == 1 ? __builtin_amdgcn_fractf(u0) : u0 - __builtin_rintf(u0);
+        a1 = WF == 1 ? __builtin_amdgcn_fractf(u1) : u1 - __builtin_rintf(u1);
+    } else if (FOLD) {             // a0, a1 = the argument in revolutions, reduced to about [-1/2, 1/2] + K
         if (PHASE != 2) {
             const float n0 = __builtin_rintf(acc[r] * f.fr[0]);
             a0 = __builtin_fmaf(acc[r], f.fr[0], -n0) + f.bs[0];
@@ -293,15 +427,21 @@ __device__ __forceinline__ void film_split_pair(const f32x16& acc, float inv_s, 
 }
 
 // whole tile at once (layer 0 and the last output tile of a layer), FiLM pairs fetched one step ahead
-template <int STORE, bool RESID>
+template <int STORE, bool RESID, int WF = 0>
 __device__ __forceinline__ void film_split(const f32x16& acc, float inv_s, const float* lbias, const float* lfr, const float* lph, int t,
                                            int h, Split2* out2, ActStore& st) {
-    FilmPair f = film_pair_load(lbias, lfr, lph, t, h, 0);
+    if constexpr (WF != 0) {
+        const FilmPair none{};
 #pragma unroll
-    for (int r = 0; r < 16; r += 2) {
-        const FilmPair fcur = f;
-        if (r + 2 < 16) f = film_pair_load(lbias, lfr, lph, t, h, r + 2);
-        film_split_pair<STORE, RESID>(acc, inv_s, fcur, t, h, r, out2, st);
+        for (int r = 0; r < 16; r += 2) film_split_pair<STORE, RESID, 0, WF>(acc, inv_s, none, t, h, r, out2, st);
+    } else {
+        FilmPair f = film_pair_load(lbias, lfr, lph, t, h, 0);
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            const FilmPair fcur = f;
+            if (r + 2 < 16) f = film_pair_load(lbias, lfr, lph, t, h, r + 2);
+            film_split_pair<STORE, RESID>(acc, inv_s, fcur, t, h, r, out2, st);
+        }
     }
 }
 
@@ -455,7 +595,7 @@ __device__ __forceinline__ TilePoint tile_of_group(const FieldArgs& a, long long
 // One block of four waves per CU (512 registers per wave), two weight units in LDS, one barrier per unit.  (Measured in round 2
 // and not kept: four slots with a barrier per two units -- no change; two waves per SIMD by a register cap -- spills, slower; a
 // two-waves-per-tile variant of this kernel -- 11.7 vs 10.9 ms)
-template <int NT, int STORE, bool HAS_RES>
+template <int NT, int STORE, bool HAS_RES, int WF>
 __global__ __launch_bounds__(256) void field_h3_kernel(FieldArgs a) {
 #ifdef CNERF_STAMPS
     unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -490,7 +630,12 @@ __global__ __launch_bounds__(256) void field_h3_kernel(FieldArgs a) {
     const int blk_per_cls = (nblk + 7 - cls) / 8;
     const long long g_begin = total_groups * cls / 8 + idx_in_cls, g_end = total_groups * (cls + 1) / 8;
 
-    const f16x8* w_units = reinterpret_cast<const f16x8*>(a.packed);  // the per-tile unit sequence, back to back
+    // the per-tile unit sequence, back to back.  WF: every image has its own copy (rows scaled by its FiLM frequencies); the copy runs
+    // one unit ahead of the MFMAs, across tile boundaries: `dma_base` is the image of the tile whose units are being requested,
+    // `next_base` the image of the group after this one -- switched when the request sequence wraps to unit 0
+    const f16x8* w_units = reinterpret_cast<const f16x8*>(a.packed);
+    const f16x8* img_units = reinterpret_cast<const f16x8*>(a.packed_img);
+    const size_t img_stride = (size_t)a.packed_img_stride;           // f16x8 fragments per image
     int staged_b = -1;                                               // image whose FiLM vectors are in LDS
     if (g_begin >= g_end) return;                                    // block-uniform
 
@@ -500,9 +645,12 @@ __global__ __launch_bounds__(256) void field_h3_kernel(FieldArgs a) {
     const int n_units = a.n_in + (a.n_mats - 1) * NT + 1;           // >= 2
     int dma_k = 0, dma_slot = 0;                                     // next unit to copy (index in the tile sequence), its slot
     int use_slot = 0;                                                // slot of the next unit to consume
+    const f16x8* dma_base = w_units;
+    const f16x8* next_base = w_units;
     auto dma_next = [&]() {       // (past the block's last tile this re-copies units nobody reads: harmless, drained at the end)
-        dma_unit_flat<NT>(w_units + (size_t)dma_k * UNIT_FR, lds + dma_slot * UNIT_FR, wave_u, lane);
+        dma_unit_flat<NT>(dma_base + (size_t)dma_k * UNIT_FR, lds + dma_slot * UNIT_FR, wave_u, lane);
         dma_k = dma_k + 1 == n_units ? 0 : dma_k + 1;
+        if (WF && dma_k == 0) dma_base = next_base;
         dma_slot = (dma_slot + 1) & (SLOTS - 1);
     };
     // every wave, at the start of every unit: this wave's share of the unit's copy must have LANDED before the barrier publishes it.
@@ -537,8 +685,9 @@ __global__ __launch_bounds__(256) void field_h3_kernel(FieldArgs a) {
     // prologue: biases and scales into LDS, the first weight unit (the first barrier publishes both); position and lookups of
     // the first tile
     for (int i = threadIdx.x; i < a.bias_floats + 2 * H; i += 256) lds_bias[i] = a.bias[i];
-    dma_next();
     TilePoint tp = tile_of_group(a, g_begin, G, wave, j);
+    if (WF) dma_base = next_base = img_units + (size_t)(tp.b + a.image0) * img_stride;
+    dma_next();
     float px, py, pz;
     tile_point(a, tp.b, tp.nn, tp.valid, h, true, px, py, pz);
     InputTile it;
@@ -549,7 +698,15 @@ __global__ __launch_bounds__(256) void field_h3_kernel(FieldArgs a) {
         const long long nn = tp.nn;
         const bool valid = tp.valid;
         BSTAMP(0);
-        if (b != staged_b && (a.freq || staged_b < 0)) {     // block-uniform
+        if (WF && b != staged_b) {                            // block-uniform: this image's accumulator starts K' S' and its 1 / S' per matrix
+            __syncthreads();                                        // nobody still reads the previous image's constants
+            const float* fsrc = a.fold + (size_t)(b + a.image0) * (a.n_mats * (H + 1));
+            for (int i = threadIdx.x; i < a.n_mats * H; i += 256) lds_k[i] = fsrc[i];
+            for (int i = threadIdx.x; i < a.n_mats; i += 256) lds_mh[i] = fsrc[a.n_mats * H + i];
+            staged_b = b;
+            __syncthreads();
+        }
+        if (!WF && b != staged_b && (a.freq || staged_b < 0)) {     // block-uniform
             __syncthreads();                                        // nobody still reads the previous image's vectors
             if (a.freq)
                 for (int i = threadIdx.x; i < a.film_stride; i += 256) {
@@ -580,6 +737,7 @@ __global__ __launch_bounds__(256) void field_h3_kernel(FieldArgs a) {
         const bool has_next = g + blk_per_cls < g_end;
         const TilePoint tn = tile_of_group(a, has_next ? g + blk_per_cls : g, G, wave, j);
         const TileRaw raw_next = tile_point_fetch(a, tn.b, tn.nn);
+        if (WF) next_base = img_units + (size_t)(tn.b + a.image0) * img_stride;
         BSTAMP(1);
 
         const float* bias = lds_bias;
@@ -604,9 +762,12 @@ __global__ __launch_bounds__(256) void field_h3_kernel(FieldArgs a) {
         {
             f32x16 acc0[NT];
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
+            for (int t = 0; t < NT; ++t) {
+                if (WF) acc0[t] = load_chan16(lds_k, t, h);       // (freq bias + phase) / 2 pi in accumulator units
+                else
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc0[t][r] = 0.0f;
+                    for (int r = 0; r < 16; ++r) acc0[t][r] = 0.0f;
+            }
             for (int tk = 0; tk < a.n_in; ++tk) {
                 if (tk > 0) input_tile_issue(a, b, tk, px, py, pz, h, it);   // tile 0 was issued during the previous head
                 const f16x8* unit = unit_begin(Younger<0>{});      // (behind the head: the next tile's lookups are in flight and needed now)
@@ -636,10 +797,10 @@ __global__ __launch_bounds__(256) void field_h3_kernel(FieldArgs a) {
             }
             BSTAMP(2);
             const bool film = a.layer_kind[0] == CNERF_LAYER_FILM;
-            const float inv_s = lds_inv_s[0];
+            const float inv_s = WF ? lds_mh[0] : lds_inv_s[0];
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                film_split<STORE, false>(acc0[t], inv_s, lds_k, lds_mh, lds_ml, t, h, &x[2 * t], st);
+                film_split<STORE, false, WF>(acc0[t], inv_s, lds_k, lds_mh, lds_ml, t, h, &x[2 * t], st);
             }
             if (STORE == STORE_F32) {
                 st.row_h += act_layer;
@@ -662,37 +823,46 @@ __global__ __launch_bounds__(256) void field_h3_kernel(FieldArgs a) {
         int m = 1;                                                   // matrix counter (scales, activation slabs)
         auto matrix = [&](const Split2* in, Split2* out, auto resid_tag, const float* fr_arg, const float* ph_arg) {
             constexpr bool RESID = decltype(resid_tag)::value;
-            const float inv_s = lds_inv_s[m];
+            const float inv_s = WF ? lds_mh[m] : lds_inv_s[m];
+            const float* ksc = lds_k + (size_t)m * H;                // WF: the accumulators' starting values of this matrix
             // folded constants of matrix m stand in for (bias, freq, phase) where the epilogue is the affine-then-sine one
             constexpr bool FOLDED = !RESID;
             const float* bias_l = FOLDED ? lds_k + (size_t)m * H : bias;
             const float* fr_l = FOLDED ? lds_mh + (size_t)m * H : fr_arg;
             const float* ph_l = FOLDED ? lds_ml + (size_t)m * H : ph_arg;
             f32x16 acc_prev;
-            FilmPair fp;
+            FilmPair fp{};
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 // since the previous unit's request: t = 0: the epilogues of the last two tiles of the matrix before (first hidden matrix:
                 // layer 0's, NT >= 2 tiles) = 16 stores; t = 1: nothing (tile 0 has no epilogue to run under it); t >= 2: tile t-2's 8
                 const f16x8* unit = t == 0 ? unit_begin(Younger<16>{}) : t == 1 ? unit_begin(Younger<0>{}) : unit_begin(Younger<8>{});
                 f32x16 acc;
+                if (WF) acc = load_chan16(ksc, t, h);
+                else
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+                    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
                 acc = h3_tile_from_lds<NT, H3_VPM>(unit, in, acc, lane, [&](int c) {
                     if (t > 0 && c < 16) {                     // epilogue of tile t-1, one pair of elements per two chunks
-                        if (!(c & 1)) fp = film_pair_load(bias_l, fr_l, ph_l, t - 1, h, c);
-                        else film_split_pair<STORE, RESID>(acc_prev, inv_s, fp, t - 1, h, c - 1, &out[2 * (t - 1)], st);
+                        if (WF) {
+                            if (c & 1) film_split_pair<STORE, RESID, 0, WF>(acc_prev, inv_s, fp, t - 1, h, c - 1, &out[2 * (t - 1)], st);
+                        } else {
+                            if (!(c & 1)) fp = film_pair_load(bias_l, fr_l, ph_l, t - 1, h, c);
+                            else film_split_pair<STORE, RESID>(acc_prev, inv_s, fp, t - 1, h, c - 1, &out[2 * (t - 1)], st);
+                        }
                     }
                 });
                 if (t > 0 && KCH < 16) {                       // narrow networks: the rest of tile t-1's elements
 #pragma unroll
-                    for (int r = KCH; r < 16; r += 2)
-                        film_split_pair<STORE, RESID>(acc_prev, inv_s, film_pair_load(bias_l, fr_l, ph_l, t - 1, h, r), t - 1, h, r,
-                                                      &out[2 * (t - 1)], st);
+                    for (int r = KCH; r < 16; r += 2) {
+                        if (WF) film_split_pair<STORE, RESID, 0, WF>(acc_prev, inv_s, fp, t - 1, h, r, &out[2 * (t - 1)], st);
+                        else film_split_pair<STORE, RESID>(acc_prev, inv_s, film_pair_load(bias_l, fr_l, ph_l, t - 1, h, r), t - 1, h, r,
+                                                           &out[2 * (t - 1)], st);
+                    }
                 }
                 acc_prev = acc;
             }
-            film_split<STORE, RESID>(acc_prev, inv_s, bias_l, fr_l, ph_l, NT - 1, h, &out[2 * (NT - 1)], st);
+            film_split<STORE, RESID, WF>(acc_prev, inv_s, bias_l, fr_l, ph_l, NT - 1, h, &out[2 * (NT - 1)], st);
             if (STORE == STORE_F32) {
                 st.row_h += act_layer;
                 st.row_c += act_layer;
@@ -770,7 +940,7 @@ static size_t h3_lds_bytes(const FieldArgs& a, int slots) {
            ((size_t)a.bias_floats + 2 * NT * 32 + 2 * (size_t)a.film_stride + 3 * (size_t)a.n_mats * NT * 32) * 4;
 }
 
-template <int NT, int STORE, bool HAS_RES>
+template <int NT, int STORE, bool HAS_RES, int WF>
 static hipError_t launch_h3_inst(const FieldArgs& a, hipStream_t stream) {
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) != hipSuccess) dev = 0;
@@ -778,20 +948,29 @@ static hipError_t launch_h3_inst(const FieldArgs& a, hipStream_t stream) {
     const size_t lds_bytes = h3_lds_bytes<NT>(a, 2);
     if (lds_bytes > LDS_LIMIT) return hipErrorInvalidValue;
     // (per launch, not once per process: the attribute is per device, and a cached flag would be unsynchronised global state)
-    if (hipError_t e = hipFuncSetAttribute((const void*)field_h3_kernel<NT, STORE, HAS_RES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT)) return e;
+    if (hipError_t e = hipFuncSetAttribute((const void*)field_h3_kernel<NT, STORE, HAS_RES, WF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT)) return e;
     const long long want = (a.total_tiles / a.tiles_per_image) * ((a.tiles_per_image + 3) / 4);
     int blocks = (int)(want < cus ? want : cus);        // one block of four waves per CU (512 registers per wave)
     if (blocks < 8) blocks = 8;
     blocks = (blocks + 7) / 8 * 8;
-    hipLaunchKernelGGL((field_h3_kernel<NT, STORE, HAS_RES>), dim3(blocks), dim3(256), lds_bytes, stream, a);
+    hipLaunchKernelGGL((field_h3_kernel<NT, STORE, HAS_RES, WF>), dim3(blocks), dim3(256), lds_bytes, stream, a);
     return hipGetLastError();
 }
 
 template <int NT, int STORE>
 static hipError_t launch_h3_nt(const FieldArgs& a, hipStream_t stream) {
-    bool res = false;
-    for (int l = 0; l < a.L; ++l) res |= a.layer_kind[l] == CNERF_LAYER_RES;
-    return res ? launch_h3_inst<NT, STORE, true>(a, stream) : launch_h3_inst<NT, STORE, false>(a, stream);
+    bool res = false, film = false;
+    for (int l = 0; l < a.L; ++l) {
+        res |= a.layer_kind[l] == CNERF_LAYER_RES;
+        film |= a.layer_kind[l] == CNERF_LAYER_FILM;
+    }
+    if constexpr (STORE != STORE_F32) {       // the image's own weight copy (cnerf_render_forward prepared it): the one-op epilogue
+        if (a.packed_img && a.fold) {
+            if (res) return launch_h3_inst<NT, STORE, true, 2>(a, stream);        // (residual networks have no FiLM layers: exact reduction)
+            return film ? launch_h3_inst<NT, STORE, false, 1>(a, stream) : launch_h3_inst<NT, STORE, false, 2>(a, stream);
+        }
+    }
+    return res ? launch_h3_inst<NT, STORE, true, 0>(a, stream) : launch_h3_inst<NT, STORE, false, 0>(a, stream);
 }
 
 static hipError_t field_impl(const FieldArgs& a, int H, hipStream_t stream) {
@@ -814,5 +993,9 @@ hipError_t H3_LAUNCH_PACK(const float* w, int n_out, int K_real, int OT, bool k_
 }
 
 hipError_t H3_LAUNCH_FIELD(const FieldArgs& a, int H, hipStream_t stream) { return H3_NS::field_impl(a, H, stream); }
+
+hipError_t H3_LAUNCH_FOLD(const FieldArgs& a, int B, int H, void* img, float* fold, float* rowf, long long img_elems, hipStream_t stream) {
+    return H3_NS::fold_impl(a, B, H, img, fold, rowf, img_elems, stream);
+}
 
 }  // namespace cnerf
