@@ -6,8 +6,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcnerf_hip.so")
-SOURCES = ["cnerf_abi.hip", "field_kernel.hip", "field_h3.hip", "ray_kernels.hip", "grad_kernels.hip", "bwd16.hip"]
-HEADERS = ["cnerf_dev.hpp", "cnerf_kernels.hpp", "field_common.hpp", "bwd16.hpp", os.path.join("..", "..", "include", "cnerf.h")]
+SOURCES = ["cnerf_abi.hip", "field_kernel.hip", "field_h3.hip", "field_pw16.hip", "ray_kernels.hip", "grad_kernels.hip", "bwd16.hip"]
+HEADERS = ["cnerf_dev.hpp", "cnerf_kernels.hpp", "field_common.hpp", "bwd16.hpp", "h3_dev.hpp", os.path.join("..", "..", "include", "cnerf.h")]
 # -ffp-contract=off: a*b+c is two roundings unless fmaf() is written (see csrc/cnerf_dev.hpp)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 
@@ -24,9 +24,9 @@ def build_library(force=False, verbose=False, extra_flags=()):
     extra_flags = tuple(extra_flags) + tuple(os.environ.get("CNERF_EXTRA_FLAGS", "").split())
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     objs, jobs = [], []
-    # (source, object, extra defines): field_h3.hip is compiled twice -- fp16x3 split kernel and the single-pass fp16 kernel
+    # (source, object, extra defines): field_h3.hip and field_pw16.hip are compiled twice -- fp16x3 split kernels and the single-pass fp16 kernels
     h1_defs = ("-DCNERF_H3_PARTS=1",) + tuple(os.environ.get("CNERF_H1_FLAGS", "").split())      # (experiments: e.g. -DCNERF_H3_OCC=2)
-    units = [(src, src.replace(".hip", ".o"), ()) for src in SOURCES] + [("field_h3.hip", "field_h1.o", h1_defs)]
+    units = [(src, src.replace(".hip", ".o"), ()) for src in SOURCES] + [("field_h3.hip", "field_h1.o", h1_defs), ("field_pw16.hip", "field_pw1.o", h1_defs)]
     for src, obj, defs in units:
         s = os.path.join(CSRC, src)
         o = os.path.join(CSRC, obj)

@@ -55,10 +55,6 @@ int check_cfg(const cnerf_cfg* c, bool need_render) {
     if (!(c->voxel_length > 0.f)) return fail(CNERF_EINVAL, "voxel_length must be > 0");
     if (c->precision != CNERF_PREC_FP32 && c->precision != CNERF_PREC_FP16X3 && c->precision != CNERF_PREC_FP16)
         return fail(CNERF_EINVAL, "precision=%d unknown", c->precision);
-    if (c->precision != CNERF_PREC_FP32)
-        for (int l = 0; l < c->L; ++l)
-            if (c->layer_kind[l] == CNERF_LAYER_PFILM)
-                return fail(CNERF_EINVAL, "precisions fp16x3 / fp16 do not cover the per-point FiLM family");
     if (!(c->drop_p >= 0.0f && c->drop_p < 1.0f)) return fail(CNERF_EINVAL, "drop_p=%g out of [0,1)", (double)c->drop_p);
     if (c->drop_p > 0.0f && c->precision != CNERF_PREC_FP32) return fail(CNERF_EINVAL, "dropout (drop_p > 0) is implemented for precision fp32 only");
     if (need_render) {
@@ -87,6 +83,19 @@ PackedLayout packed_layout(const cnerf_cfg* c) {
     const size_t NT = c->H / 32;
     const size_t tile = 4 * 64 * 4;  // floats per (t, tk) pair
     PackedLayout p{0, 0, 0, 0, 0};
+    if (c->layer_kind[0] == CNERF_LAYER_PFILM && c->precision != CNERF_PREC_FP32) {
+        // field_pw16.hip: weight units in consumption order -- Wm1 | W_0 | layer 0: per tile (freq rows, phase rows) | layers >= 1: per
+        // tile (freq rows, W_l, phase rows) | head; units multiplied by m have 16 k-chunks, the others 2 NT.  Behind them the
+        // constants of pw16_consts_kernel, then the 1 / S and max|W| slots of the 3 L + 2 packed matrices
+        const size_t parts = c->precision == CNERF_PREC_FP16 ? 1 : 2;
+        const size_t frag = 64 * 8 / 2;                     // floats per (tile, k-chunk, part)
+        const size_t big = 16 * parts * frag, small = 2 * NT * parts * frag;
+        p.n_in = 1;
+        p.k0 = 3;
+        p.weight_floats = big + small + NT * 2 * big + (size_t)(c->L - 1) * NT * (2 * big + small) + small;
+        p.bias_floats = 256 + 3 * (size_t)c->L * c->H + 4 + (2 + 2 * (size_t)c->L + 3) / 4 * 4 + (2 * (3 * (size_t)c->L + 2) + 3) / 4 * 4;
+        return p;
+    }
     if (c->layer_kind[0] == CNERF_LAYER_PFILM) {   // mapping hidden | per layer (main, freq rows, phase rows) | head
         p.n_in = 1;
         p.k0 = 3;
@@ -215,6 +224,8 @@ void set_dropout(FieldArgs& a, const cnerf_cfg* c, const uint8_t* mask, uint32_t
 }
 
 hipError_t launch_forward(const FieldArgs& a, const cnerf_cfg* c, hipStream_t stream) {
+    if (c->layer_kind[0] == CNERF_LAYER_PFILM && c->precision != CNERF_PREC_FP32)
+        return c->precision == CNERF_PREC_FP16 ? launch_field_pw1(a, c->H, stream) : launch_field_pw3(a, c->H, stream);
     if (c->precision == CNERF_PREC_FP16X3) return launch_field_h3(a, c->H, stream);
     if (c->precision == CNERF_PREC_FP16) return launch_field_h1(a, c->H, stream);
     return launch_field(a, c->H, stream);
@@ -300,6 +311,43 @@ int cnerf_pack_field(const cnerf_cfg* cfg, const cnerf_field_params* p, float* p
         if (cfg->C != 32 || cfg->n_levels > 1) return fail(CNERF_EINVAL, "per-point FiLM: a single 32-channel feature volume is supported");
         if (!p->map_w1 || !p->map_b1 || !p->map_w2 || !p->map_b2 || !p->w_final || !p->b_final)
             return fail(CNERF_EINVAL, "pack_field: mapping network / head is NULL");
+        for (int l = 0; l < cfg->L; ++l)
+            if (!p->w[l] || !p->b[l]) return fail(CNERF_EINVAL, "pack_field: layer %d weight/bias is NULL", l);
+    }
+    if (cfg->layer_kind[0] == CNERF_LAYER_PFILM && cfg->precision != CNERF_PREC_FP32) {      // field_pw16.hip, see packed_layout()
+        const size_t parts = cfg->precision == CNERF_PREC_FP16 ? 1 : 2;
+        const size_t frag = 64 * 8 / 2;
+        const size_t big = 16 * parts * frag, small = 2 * (size_t)NT * parts * frag;
+        auto pack16 = cfg->precision == CNERF_PREC_FP16 ? launch_pack_h1 : launch_pack_h3;
+        const int L = cfg->L, n_slots = 3 * L + 2;
+        float* consts = packed + pl.weight_floats;
+        float* inv_s = consts + 256 + 3 * (size_t)L * H + 4 + (2 + 2 * (size_t)L + 3) / 4 * 4;     // [Wm1 | per layer: W_l, freq rows, phase rows | head]
+        float* wmax = inv_s + n_slots;
+        const size_t LH = (size_t)L * H;
+        if (hipError_t e = pack16(p->map_w1, 256, cfg->C, 8, true, wdst, inv_s, wmax, stream, 0)) return hip_fail(e, "pack_h3");
+        wdst += big;
+        if (hipError_t e = pack16(p->w[0], H, 3, NT, true, wdst, inv_s + 1, wmax + 1, stream, 0)) return hip_fail(e, "pack_h3");
+        wdst += small;
+        for (int l = 0; l < L; ++l) {
+            // the tiles of the layer's three matrices interleaved per output tile: [freq rows t | W_l t (l >= 1) | phase rows t]
+            const long long t_stride = 16 + 16 + (l ? 2 * NT : 0);          // fragment pairs (one per k-chunk) per output tile
+            const float* wf = p->map_w2 + (size_t)l * H * 256;
+            const float* wp = p->map_w2 + (LH + (size_t)l * H) * 256;
+            float* d = wdst;
+            if (hipError_t e = pack16(wf, H, 256, NT, false, d, inv_s + 2 + 3 * l, wmax + 2 + 3 * l, stream, t_stride)) return hip_fail(e, "pack_h3");
+            d += big;
+            if (l) {
+                if (hipError_t e = pack16(p->w[l], H, H, NT, false, d, inv_s + 1 + 3 * l, wmax + 1 + 3 * l, stream, t_stride)) return hip_fail(e, "pack_h3");
+                d += small;
+            }
+            if (hipError_t e = pack16(wp, H, 256, NT, false, d, inv_s + 3 + 3 * l, wmax + 3 + 3 * l, stream, t_stride)) return hip_fail(e, "pack_h3");
+            wdst += (size_t)NT * (2 * big + (l ? small : 0));
+        }
+        if (hipError_t e = pack16(p->w_final, 4, H, 1, false, wdst, inv_s + 3 * L + 1, wmax + 3 * L + 1, stream, 0)) return hip_fail(e, "pack_h3");
+        if (hipError_t e = launch_pw16_consts(p, L, H, inv_s, consts, stream)) return hip_fail(e, "pw16_consts");
+        return CNERF_OK;
+    }
+    if (cfg->layer_kind[0] == CNERF_LAYER_PFILM) {
         auto cp = [&](const float* src, size_t n) { return hipMemcpyAsync(bdst, src, n * sizeof(float), hipMemcpyDeviceToDevice, stream); };
         if (hipError_t e = launch_pack_matrix(p->map_w1, 256, cfg->C, 8, wdst, stream)) return hip_fail(e, "pack_matrix");
         wdst += 8 * tile;
@@ -346,7 +394,7 @@ int cnerf_pack_field(const cnerf_cfg* cfg, const cnerf_field_params* p, float* p
             for (int half = 0; half < (res ? 2 : 1); ++half) {
                 const float* w = half ? p->w2[l] : p->w[l];
                 const float* b = half ? p->b2[l] : p->b[l];
-                if (hipError_t e = pack16(w, H, K, NT, l == 0, wdst, inv_scale + m, wmax + m, stream)) return hip_fail(e, "pack_h3");
+                if (hipError_t e = pack16(w, H, K, NT, l == 0, wdst, inv_scale + m, wmax + m, stream, 0)) return hip_fail(e, "pack_h3");
                 wdst += (size_t)NT * ((K + 31) / 32 * 2) * parts * frag;
                 if (hipError_t e = hipMemcpyAsync(bdst, b, H * sizeof(float), hipMemcpyDeviceToDevice, stream)) return hip_fail(e, "bias copy");
                 bdst += H;
@@ -354,7 +402,7 @@ int cnerf_pack_field(const cnerf_cfg* cfg, const cnerf_field_params* p, float* p
             }
         }
         if (!p->w_final || !p->b_final) return fail(CNERF_EINVAL, "pack_field: head is NULL");
-        if (hipError_t e = pack16(p->w_final, 4, H, 1, false, wdst, inv_scale + m, wmax + m, stream)) return hip_fail(e, "pack_h3");
+        if (hipError_t e = pack16(p->w_final, 4, H, 1, false, wdst, inv_scale + m, wmax + m, stream, 0)) return hip_fail(e, "pack_h3");
         if (hipError_t e = hipMemcpyAsync(bdst, p->b_final, 4 * sizeof(float), hipMemcpyDeviceToDevice, stream)) return hip_fail(e, "bias copy");
         bdst = packed + pl.weight_floats + pl.bias_floats;
         if (hipError_t e = launch_fill(bdst, 1.0f, H, stream)) return hip_fail(e, "fill");
@@ -542,6 +590,7 @@ int cnerf_render_forward(const cnerf_cfg* cfg, const cnerf_volumes* vols, const 
     if (keep) {
         if (cfg->precision != CNERF_PREC_FP16X3 && cfg->precision != CNERF_PREC_FP16)
             return fail(CNERF_EINVAL, "render_forward: act16 needs precision CNERF_PREC_FP16X3 or CNERF_PREC_FP16");
+        if (cfg->layer_kind[0] == CNERF_LAYER_PFILM) return fail(CNERF_EINVAL, "render_forward: act16 is not available for the per-point FiLM family");
         if (!aux->act16[0].feat || !aux->act16[0].c || (hier && (!aux->act16[1].feat || !aux->act16[1].h || !aux->act16[1].c)))
             return fail(CNERF_EINVAL, "render_forward: act16 is incomplete");
     }
@@ -652,6 +701,8 @@ int cnerf_field_backward(const cnerf_cfg* cfg, int32_t pass, int32_t image0, int
     if (int rc = check_cfg(cfg, true)) return rc;
     if (image0 < 0 || n_images < 1 || image0 + n_images > cfg->B) return fail(CNERF_EINVAL, "field_backward: image range out of [0,B)");
     if (pass < 0 || pass > 2) return fail(CNERF_EINVAL, "field_backward: pass must be 0 (coarse), 1 (fine) or 2 (explicit points)");
+    if (cfg->layer_kind[0] == CNERF_LAYER_PFILM && cfg->precision != CNERF_PREC_FP32)
+        return fail(CNERF_EINVAL, "field_backward: the per-point FiLM family's fp32 chain needs a cfg (and packed weights) of precision fp32");
     if (!vols || !packed || !packed_t || !cam2world || !grad_rgb_sigma || !saved_rgb_sigma || !act_feat || !act_h || !act_c ||
         !act_g || !act_go || !grad_vols)
         return fail(CNERF_EINVAL, "field_backward: NULL argument");

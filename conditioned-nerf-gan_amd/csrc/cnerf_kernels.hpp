@@ -83,10 +83,16 @@ hipError_t launch_field_h1(const FieldArgs& a, int H, hipStream_t stream);      
 // per-image weight folding of the fp16 kernels (field_h3.hip): img (B, img_elems fp16), fold (B, n_mats * (H + 1)), rowf (B, n_mats, H) scratch
 hipError_t launch_fold_h3(const FieldArgs& a, int B, int H, void* img, float* fold, float* rowf, long long img_elems, hipStream_t stream);
 hipError_t launch_fold_h1(const FieldArgs& a, int B, int H, void* img, float* fold, float* rowf, long long img_elems, hipStream_t stream);
+// t_stride: fragment pairs (one per (output tile, k-chunk)) between successive output tiles in dst; 0 = dense
 hipError_t launch_pack_h1(const float* w, int n_out, int K_real, int OT, bool k_outer, void* dst, float* inv_scale_slot, float* wmax_slot,
-                          hipStream_t stream);
+                          hipStream_t stream, long long t_stride = 0);
 hipError_t launch_pack_h3(const float* w, int n_out, int K_real, int OT, bool k_outer, void* dst, float* inv_scale_slot, float* wmax_slot,
-                          hipStream_t stream);
+                          hipStream_t stream, long long t_stride = 0);
+// field_pw16.hip (compiled twice like field_h3.hip): the per-point FiLM family (TALLSIREN) on the fp16 matrix pipe
+hipError_t launch_field_pw3(const FieldArgs& a, int H, hipStream_t stream);
+hipError_t launch_field_pw1(const FieldArgs& a, int H, hipStream_t stream);
+// starting values of the accumulators (biases in accumulator units) and the epilogue's scalars from the raw biases and the 1 / S slots
+hipError_t launch_pw16_consts(const cnerf_field_params* p, int L, int H, const float* inv_s, float* consts, hipStream_t stream);
 hipError_t launch_field_backward(const FieldArgs& a, int H, hipStream_t stream);
 hipError_t launch_pack_head_t(const float* w, int H, float* dst, hipStream_t stream);
 hipError_t launch_pack_head(const float* w, int H, float* dst, hipStream_t stream);

@@ -29,6 +29,7 @@
 #include "cnerf_kernels.hpp"
 #include "field_common.hpp"
 #include "bwd16.hpp"
+#include "h3_dev.hpp"
 #include <stdlib.h>
 
 // This translation unit is compiled TWICE (build.py): CNERF_H3_PARTS = 2 (default) is the fp16x3 kernel described above,
@@ -36,63 +37,9 @@
 // instead of three, no remainder arithmetic -- plain fp16 products with fp32 accumulation, the numerics class of the reference's
 // own GPU path (torch.cuda.amp.autocast, utils.py:327,643) and of BASELINE config 5 ("bf16 SIREN on MFMA"; fp16 rather than bf16:
 // same MFMA rate, 8x smaller operand rounding, and the operands here are bounded -- sines -- or scaled by a power of two).  Same
-// kernel structure, same packed-stream order with one plane per fragment pair, its own symbol names (inner namespace).
-#ifndef CNERF_H3_PARTS
-#define CNERF_H3_PARTS 2
-#endif
-#if CNERF_H3_PARTS == 1
-#define H3_NS h1
-#define H3_LAUNCH_FIELD launch_field_h1
-#define H3_LAUNCH_PACK launch_pack_h1
-#define H3_LAUNCH_FOLD launch_fold_h1
-#else
-#define H3_NS h3
-#define H3_LAUNCH_FIELD launch_field_h3
-#define H3_LAUNCH_PACK launch_pack_h3
-#define H3_LAUNCH_FOLD launch_fold_h3
-#endif
-
+// kernel structure, same packed-stream order with one plane per fragment pair, its own symbol names (inner namespace; h3_dev.hpp).
 namespace cnerf {
 namespace H3_NS {
-
-constexpr int PARTS = CNERF_H3_PARTS;
-
-struct Split2 {          // eight fp32 values as PARTS fp16 fragments; dword d of a fragment = elements 2d (low half), 2d+1
-    u32x4 p[PARTS];
-    __device__ __forceinline__ f16x8 frag(int k) const { return __builtin_bit_cast(f16x8, p[k]); }
-};
-
-// two fp32 -> packed fp16 pair, rounded toward zero (one v_cvt_pkrtz_f16_f32; saturates instead of overflowing)
-__device__ __forceinline__ uint32_t pk_rtz(float a, float b) { return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(a, b)); }
-
-// Two parts of two consecutive values into dword D of the two fragments.  hi = value truncated to 11 significant bits
-// (the fp32 with its 13 low mantissa bits cleared IS that fp16 value over fp16's normal range; below 2^-14 the two differ
-// by < 6e-8 absolute, nothing at the scale of activations and scaled weights), lo = remainder, again truncated.
-template <int D>
-__device__ __forceinline__ void split_pair(float v0, float v1, Split2& s) {
-    if constexpr (PARTS == 1) {
-        s.p[0][D] = pk_f16(v0, v1);          // the only part: round to nearest (truncation would bias every product low)
-    } else {
-        s.p[0][D] = pk_rtz(v0, v1);
-        // (a v_fma_mix_f32 against the packed half itself is one op instead of and + sub but measured no faster)
-        const float r0 = v0 - __uint_as_float(__float_as_uint(v0) & 0xffffe000u);
-        const float r1 = v1 - __uint_as_float(__float_as_uint(v1) & 0xffffe000u);
-        s.p[PARTS - 1][D] = pk_rtz(r0, r1);
-    }
-}
-
-// layer-0 inputs (looked-up features, positions) are not bounded like sine outputs: clamp to fp16's range first
-__device__ __forceinline__ Split2 split8_clamped(const float* v) {
-    float c[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) c[i] = __builtin_amdgcn_fmed3f(v[i], -65504.0f, 65504.0f);
-    Split2 s;
-    split_pair<0>(c[0], c[1], s);
-    split_pair<1>(c[2], c[3], s);
-    split_pair<2>(c[4], c[5], s);
-    split_pair<3>(c[6], c[7], s);
-    return s;
-}
 
 // ---------------------------------------------------------------------------------------------------------------
 // packing: fragment index ((t*KC + c)*2 + part)*64 + lane (layer 0: (((c>>1)*OT + t)*2 + (c&1))*2 + part), 8 fp16 each:
@@ -115,8 +62,10 @@ __device__ __forceinline__ float pow2_scale(float wmax) {
     return ldexpf(1.0f, e);
 }
 
-__global__ void pack_h3_kernel(const float* __restrict__ w, int n_out, int K_real, int KC, int OT, int k_outer, const uint32_t* wmax_slot,
-                               float* inv_scale_slot, _Float16* __restrict__ dst) {
+// t_stride: fragment pairs between successive output tiles in dst (KC: dense; larger: the tiles of several matrices interleaved,
+// field_pw16.hip)
+__global__ void pack_h3_kernel(const float* __restrict__ w, int n_out, int K_real, int KC, int OT, int k_outer, long long t_stride,
+                               const uint32_t* wmax_slot, float* inv_scale_slot, _Float16* __restrict__ dst) {
     const float S = pow2_scale(__uint_as_float(*wmax_slot));
     if (blockIdx.x == 0 && threadIdx.x == 0) *inv_scale_slot = 1.0f / S;
     const long long total = (long long)OT * KC * 64 * 8;          // one thread per (t, c, lane, j): writes both parts
@@ -131,7 +80,7 @@ __global__ void pack_h3_kernel(const float* __restrict__ w, int n_out, int K_rea
         const _Float16 a1 = (_Float16)(v - (float)a0);
         // fragment pair index: (t, c) row-major, or -- layer 0 -- input tile outermost so that the two chunks of one input tile
         // for all output tiles form one contiguous weight unit
-        const size_t pair = k_outer ? ((size_t)(c >> 1) * OT + t) * 2 + (c & 1) : (size_t)tc;
+        const size_t pair = k_outer ? ((size_t)(c >> 1) * OT + t) * 2 + (c & 1) : (size_t)t * t_stride + c;
         const size_t base = (pair * PARTS) * 64 * 8 + (size_t)lane * 8 + j;
         dst[base] = a0;
         if (PARTS == 2) dst[base + 64 * 8] = a1;
@@ -139,7 +88,7 @@ __global__ void pack_h3_kernel(const float* __restrict__ w, int n_out, int K_rea
 }
 
 static hipError_t pack_impl(const float* w, int n_out, int K_real, int OT, bool k_outer, void* dst, float* inv_scale_slot, float* wmax_slot,
-                            hipStream_t stream) {
+                            hipStream_t stream, long long t_stride) {
     if (hipError_t e = hipMemsetAsync(wmax_slot, 0, sizeof(float), stream)) return e;
     const long long n = (long long)n_out * K_real;
     long long rb = (n + 255) / 256;
@@ -149,8 +98,8 @@ static hipError_t pack_impl(const float* w, int n_out, int K_real, int OT, bool 
     const long long total = (long long)OT * KC * 64 * 8;
     long long blocks = (total + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(pack_h3_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, w, n_out, K_real, KC, OT, k_outer ? 1 : 0, (const uint32_t*)wmax_slot,
-                       inv_scale_slot, (_Float16*)dst);
+    hipLaunchKernelGGL(pack_h3_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, w, n_out, K_real, KC, OT, k_outer ? 1 : 0,
+                       t_stride > 0 ? t_stride : (long long)KC, (const uint32_t*)wmax_slot, inv_scale_slot, (_Float16*)dst);
     return hipGetLastError();
 }
 
@@ -322,9 +271,6 @@ constexpr int STORE_NONE = 0, STORE_F32 = 1, STORE_TB16 = 2;
 // two), FiLM with product and sum rounded separately like the reference (a plain sine layer runs with freq = 1,
 // phase = 0, which is exact -- one branch-free code path), sine, split into the fragments of the chunk pair `out2`
 // (element r of the tile is element r & 7 of chunk r >> 3).  Pairs of a tile must arrive in order r = 0, 2, 4, ...
-// the two fp16 halves of a packed pair, widened (exact)
-__device__ __forceinline__ float half_lo(uint32_t u) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(u & 0xffffu)); }
-__device__ __forceinline__ float half_hi(uint32_t u) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(u >> 16)); }
 
 // RESID (second matrix of a residual block, siren.py:218-230): the slot the result goes to still holds the block's input
 // x as its two fp16 parts; x = hi + lo is added to W2 y + b2 before the sine, and the slot is overwritten.
@@ -462,13 +408,6 @@ struct H3Lds {
     static constexpr int PER_WAVE = PIECES / 4;        // pieces each wave copies
 };
 
-// One wave instruction moves 1 KiB: lane i's 16 bytes from src_lane land at lds_dst + OFF + 16 i (the instruction offset
-// applies to the global and to the LDS address alike).
-template <int OFF>
-__device__ __forceinline__ void dma_piece(const f16x8* src_lane, f16x8* lds_dst) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_lane,
-                                     (__attribute__((address_space(3))) void*)lds_dst, 16, OFF, 0);
-}
 
 // every weight unit is contiguous in the packed stream (pack_h3_kernel); wave w moves the
 // pieces [w*PER_WAVE, (w+1)*PER_WAVE), four per base address (instruction offsets 0, 1, 2, 3 KiB)
@@ -487,16 +426,6 @@ __device__ __forceinline__ void dma_unit_flat(const f16x8* __restrict__ src, f16
         if (4 * q + 3 < PW) dma_piece<3072>(sq, dq);
     }
 }
-#if CNERF_H3_PARTS == 1
-#define H3_MFMA3(acc, a, xs) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], (xs).frag(0), acc, 0, 0, 0)
-#else
-#define H3_MFMA3(acc, a, xs)                                                                  \
-    do {                                                                                       \
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], (xs).frag(0), acc, 0, 0, 0);        \
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], (xs).frag(1), acc, 0, 0, 0);        \
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], (xs).frag(0), acc, 0, 0, 0);        \
-    } while (0)
-#endif
 
 // acc (one 32-row output tile) += W_unit * x, A fragments from the LDS copy of the unit; the caller's functor runs once
 // per k-chunk (the pipelined epilogue of the previous output tile).  VALU_PER_MFMA sizes the interleave groups.
@@ -988,8 +917,8 @@ static hipError_t field_impl(const FieldArgs& a, int H, hipStream_t stream) {
 }  // namespace H3_NS
 
 hipError_t H3_LAUNCH_PACK(const float* w, int n_out, int K_real, int OT, bool k_outer, void* dst, float* inv_scale_slot, float* wmax_slot,
-                          hipStream_t stream) {
-    return H3_NS::pack_impl(w, n_out, K_real, OT, k_outer, dst, inv_scale_slot, wmax_slot, stream);
+                          hipStream_t stream, long long t_stride) {
+    return H3_NS::pack_impl(w, n_out, K_real, OT, k_outer, dst, inv_scale_slot, wmax_slot, stream, t_stride);
 }
 
 hipError_t H3_LAUNCH_FIELD(const FieldArgs& a, int H, hipStream_t stream) { return H3_NS::field_impl(a, H, stream); }

@@ -50,12 +50,10 @@ def volumes_struct(levels):
 def precision_of(net):
     """Forward arithmetic of `net`: its `.precision` attribute -- "fp32" (exact fp32 MFMA), "fp16x3" (fp32-accurate three-way
     fp16 split, same parity gate) or "fp16" (plain fp16 products with fp32 sums: the reference's autocast class, ~1e-3) -- the
-    fp16 kernels only where they exist (FiLM / plain-sine / residual layers; the per-point FiLM family runs in fp32)."""
+    every layer family has the three kernels (FiLM / plain-sine / residual: field_h3.hip, per-point FiLM: field_pw16.hip)."""
     p = getattr(net, "precision", "fp32")
     if p not in L.PREC_CODE:
         raise L.CnerfError(f"unknown precision {p!r}")
-    if p != "fp32" and any(k not in ("film", "sine", "res") for k in net.spec.layers):
-        return "fp32"
     return p
 
 
@@ -523,7 +521,9 @@ def render_backward(net, o, levels, freq, phase, cam2world, rng, saved, grad_pix
     c_rs, c_z, f_rs, f_z = saved[:4]
     grad_pixels = _f32(grad_pixels)
     grad_depth = _f32(grad_depth) if grad_depth is not None else None
-    if net.spec.layers[0] == "pfilm":
+    if net.spec.layers[0] == "pfilm":      # (fp32 chain: the activation-storing re-run and its packed weights are the fp32 kernel's)
+        cfg = make_cfg(net, B, levels, R, S, o["fov"], o["ray_start"], o["ray_end"], o["noise_std"], hier, o["white_back"], o["last_back"],
+                       o["clamp_mode"], precision="fp32", philox=rng.get("philox"), drop=drop_of(rng))
         gc = torch.empty_like(c_rs)
         gf = torch.empty_like(f_rs) if hier else None
         eps_final = _f32(rng.get("eps_final")) if o["noise_std"] != 0 else None

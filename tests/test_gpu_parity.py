@@ -49,7 +49,7 @@ def make_generator(g, dev):
     return gen
 
 
-SPLIT_FIXTURES = [n for n in GOLDEN_NAMES if n.startswith(("short_fg", "tall_fg", "double_fg", "single_dg", "short_f_", "tall_dgx", "short_pyrmd", "short_fres", "tall_dres"))]
+SPLIT_FIXTURES = [n for n in GOLDEN_NAMES if n.startswith(("short_fg", "tall_fg", "double_fg", "single_dg", "short_f_", "tall_dgx", "short_pyrmd", "short_fres", "tall_dres", "tallsiren"))]
 
 
 @pytest.mark.parametrize("name", SPLIT_FIXTURES)
