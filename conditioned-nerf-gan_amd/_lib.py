@@ -8,7 +8,7 @@ LIB_PATH = os.path.join(HERE, "libcnerf_hip.so")
 
 MAX_LAYERS = 16
 MAX_LEVELS = 4
-ABI_VERSION = 6
+ABI_VERSION = 7
 F_HIERARCHICAL, F_WHITE_BACK, F_LAST_BACK, F_SOFTPLUS, F_SIGMOID_RGB, F_INPUT_XYZ = 1, 2, 4, 8, 16, 32
 PREC_FP32, PREC_FP16, PREC_FP16X3 = 0, 1, 2
 PREC_CODE = {"fp32": PREC_FP32, "fp16": PREC_FP16, "fp16x3": PREC_FP16X3}
@@ -38,7 +38,8 @@ class FieldParams(C.Structure):
 
 class FieldParamGrads(C.Structure):
     _fields_ = [("w", C.c_void_p * MAX_LAYERS), ("b", C.c_void_p * MAX_LAYERS), ("w2", C.c_void_p * MAX_LAYERS),
-                ("b2", C.c_void_p * MAX_LAYERS), ("w_final", C.c_void_p), ("b_final", C.c_void_p)]
+                ("b2", C.c_void_p * MAX_LAYERS), ("w_final", C.c_void_p), ("b_final", C.c_void_p),
+                ("map_w1", C.c_void_p), ("map_b1", C.c_void_p), ("map_w2", C.c_void_p), ("map_b2", C.c_void_p)]
 
 
 class Saved(C.Structure):

@@ -93,7 +93,7 @@ PackedLayout packed_layout(const cnerf_cfg* c) {
         p.n_in = 1;
         p.k0 = 3;
         p.weight_floats = big + small + NT * 2 * big + (size_t)(c->L - 1) * NT * (2 * big + small) + small;
-        p.bias_floats = 256 + 3 * (size_t)c->L * c->H + 4 + (2 + 2 * (size_t)c->L + 3) / 4 * 4 + (2 * (3 * (size_t)c->L + 2) + 3) / 4 * 4;
+        p.bias_floats = 256 + 3 * (size_t)c->L * c->H + 4 + (2 + 4 * (size_t)c->L + 3) / 4 * 4 + (2 * (3 * (size_t)c->L + 2) + 3) / 4 * 4;
         return p;
     }
     if (c->layer_kind[0] == CNERF_LAYER_PFILM) {   // mapping hidden | per layer (main, freq rows, phase rows) | head
@@ -321,7 +321,7 @@ int cnerf_pack_field(const cnerf_cfg* cfg, const cnerf_field_params* p, float* p
         auto pack16 = cfg->precision == CNERF_PREC_FP16 ? launch_pack_h1 : launch_pack_h3;
         const int L = cfg->L, n_slots = 3 * L + 2;
         float* consts = packed + pl.weight_floats;
-        float* inv_s = consts + 256 + 3 * (size_t)L * H + 4 + (2 + 2 * (size_t)L + 3) / 4 * 4;     // [Wm1 | per layer: W_l, freq rows, phase rows | head]
+        float* inv_s = consts + 256 + 3 * (size_t)L * H + 4 + (2 + 4 * (size_t)L + 3) / 4 * 4;     // [Wm1 | per layer: W_l, freq rows, phase rows | head]
         float* wmax = inv_s + n_slots;
         const size_t LH = (size_t)L * H;
         if (hipError_t e = pack16(p->map_w1, 256, cfg->C, 8, true, wdst, inv_s, wmax, stream, 0)) return hip_fail(e, "pack_h3");
@@ -790,9 +790,30 @@ int chain16_layout(const cnerf_cfg* c, Chain16Layout& l) {
 }
 }  // namespace
 
+namespace {
+// per-point FiLM family (chain_pw16.hip): [unit stream][head^T: NT fragments x 64 lanes][winv: 2 L + 2][anorm: L + 1][max|W| scratch: 2 L + 2]
+struct PwChainLayout {
+    size_t head_off, winv_off, anorm_off, wmax_off, total;
+};
+PwChainLayout pw_chain_layout(const cnerf_cfg* c) {
+    PwChainLayout l;
+    const size_t NT = c->H / 32, L = c->L;
+    l.head_off = align256(pw_chain_units_bytes(c->L, c->H));
+    l.winv_off = l.head_off + align256(NT * 1024);
+    l.anorm_off = l.winv_off + align256((2 * L + 2) * sizeof(float));
+    l.wmax_off = l.anorm_off + align256((L + 1) * sizeof(float));
+    l.total = l.wmax_off + align256((2 * L + 2) * sizeof(uint32_t));
+    return l;
+}
+}  // namespace
+
 int cnerf_backward16_bytes(const cnerf_cfg* cfg, size_t* packed16) {
     g_err[0] = 0;
     if (int rc = check_cfg(cfg, false)) return rc;
+    if (cfg->layer_kind[0] == CNERF_LAYER_PFILM) {
+        if (packed16) *packed16 = pw_chain_layout(cfg).total;
+        return CNERF_OK;
+    }
     Chain16Layout l;
     if (int rc = chain16_layout(cfg, l)) return rc;
     if (packed16) *packed16 = l.total;
@@ -802,6 +823,18 @@ int cnerf_backward16_bytes(const cnerf_cfg* cfg, size_t* packed16) {
 int cnerf_pack_field_chain16(const cnerf_cfg* cfg, const cnerf_field_params* p, void* packed16, void* stream_) {
     g_err[0] = 0;
     if (int rc = check_cfg(cfg, false)) return rc;
+    if (cfg->layer_kind[0] == CNERF_LAYER_PFILM) {
+        if (!p || !packed16 || !p->w_final || !p->map_w1 || !p->map_w2) return fail(CNERF_EINVAL, "pack_field_chain16: NULL argument");
+        for (int l = 1; l < cfg->L; ++l)
+            if (!p->w[l]) return fail(CNERF_EINVAL, "pack_field_chain16: layer %d weight is NULL", l);
+        if (cfg->C != 32 || cfg->n_levels > 1) return fail(CNERF_EINVAL, "per-point FiLM: a single 32-channel feature volume is supported");
+        const PwChainLayout l = pw_chain_layout(cfg);
+        char* base = (char*)packed16;
+        if (hipError_t e = launch_pack_pw_chain(p, cfg->L, cfg->H, base, base + l.head_off, (float*)(base + l.winv_off), (float*)(base + l.anorm_off),
+                                                (uint32_t*)(base + l.wmax_off), (hipStream_t)stream_))
+            return hip_fail(e, "pack_pw_chain");
+        return CNERF_OK;
+    }
     Chain16Layout l;
     if (int rc = chain16_layout(cfg, l)) return rc;
     if (!p || !packed16 || !p->w_final) return fail(CNERF_EINVAL, "pack_field_chain16: NULL argument");
@@ -930,6 +963,7 @@ namespace {
 struct BackwardLayout {
     size_t gc, gf;                                   // d loss / d rgb_sigma of the coarse / fine samples, whole call
     size_t a_feat, a_h, a_c, a_g, a_go;              // chunk buffers (a_feat / a_h / a_c absent when the forward kept its activations)
+    size_t a_amax;                                   // per-point FiLM family: (L, T * 32) floats
     size_t gmax, scales;                             // fp16: sampled maxima (n_mats + 1 uint32), {S, 1/S} pairs (n_mats + 1)
     size_t dwarg, cs, dwh, csh;                      // per-image reductions of one matrix: (cnt, H, 32 * max tiles), (cnt, H), (cnt, 4, H), (cnt, 4)
     size_t total;
@@ -937,10 +971,38 @@ struct BackwardLayout {
 };
 int backward_layout(const cnerf_cfg* c, int bprec, int cnt, bool have_act16, BackwardLayout& L) {
     if (bprec != CNERF_PREC_FP32 && bprec != CNERF_PREC_FP16) return fail(CNERF_EINVAL, "render_backward: backward_precision must be CNERF_PREC_FP32 or CNERF_PREC_FP16");
-    if (c->layer_kind[0] == CNERF_LAYER_PFILM)
-        return fail(CNERF_ENOSYS, "render_backward: the per-point FiLM family finishes its mapping-MLP gradients with library GEMMs on the host "
-                                  "(cnerf_field_backward + cnerf_weight_grad + cnerf_scatter_features)");
+    if (c->layer_kind[0] == CNERF_LAYER_PFILM && bprec != CNERF_PREC_FP16)
+        return fail(CNERF_ENOSYS, "render_backward: the per-point FiLM family's exact fp32 backward finishes its mapping-MLP gradients with library "
+                                  "GEMMs on the host (cnerf_field_backward + cnerf_weight_grad + cnerf_scatter_features); backward_precision fp16 runs here");
     if (cnt < 1 || cnt > c->B) return fail(CNERF_EINVAL, "render_backward: images_per_chunk=%d out of [1,B]", cnt);
+    if (c->layer_kind[0] == CNERF_LAYER_PFILM) {      // chain_pw16.hip: three stored derivatives and three gradient slabs per layer, m and g_mpre
+        if (have_act16) return fail(CNERF_EINVAL, "render_backward: kept activations are not available for the per-point FiLM family");
+        if (c->precision != CNERF_PREC_FP16X3) return fail(CNERF_EINVAL, "render_backward: the fp16 backward re-runs the fp16x3 forward (cfg->precision)");
+        const size_t H = c->H, NT = H / 32, Lc = c->L, npi = (size_t)c->R * c->R * c->S, tpi = (npi + 31) / 32;
+        const size_t N = (size_t)c->B * npi, T = (size_t)cnt * tpi;
+        const bool hier = c->flags & CNERF_F_HIERARCHICAL;
+        L.n_in = 2;
+        L.k0 = 3;
+        L.n_mats = c->L;
+        size_t off = 0;
+        auto take = [&](size_t bytes) { const size_t o = off; off += align256(bytes); return o; };
+        L.gc = take(N * 4 * sizeof(float));
+        L.gf = take(hier ? N * 4 * sizeof(float) : 0);
+        L.a_feat = take(T * 2 * 2048);
+        L.a_h = take((Lc * NT + 8) * T * 2048);
+        L.a_c = take(3 * Lc * NT * T * 2048);
+        L.a_amax = take(Lc * T * 32 * sizeof(float));
+        L.a_g = take((3 * Lc * NT + 8) * T * 2048);
+        L.a_go = take(T * 2048);
+        L.gmax = take((3 * Lc + 2) * sizeof(uint32_t));
+        L.scales = take(2 * (3 * Lc + 2) * sizeof(float));
+        L.dwarg = take((size_t)cnt * 256 * 256 * sizeof(float));
+        L.cs = take((size_t)cnt * 256 * sizeof(float));
+        L.dwh = take((size_t)cnt * 4 * H * sizeof(float));
+        L.csh = take((size_t)cnt * 4 * sizeof(float));
+        L.total = off;
+        return CNERF_OK;
+    }
     if (have_act16 && (bprec != CNERF_PREC_FP16 || cnt != c->B)) return fail(CNERF_EINVAL, "render_backward: kept activations need the fp16 backward and images_per_chunk = B");
     if (bprec == CNERF_PREC_FP16 && c->precision != CNERF_PREC_FP16X3) return fail(CNERF_EINVAL, "render_backward: the fp16 backward re-runs the fp16x3 forward (cfg->precision)");
     const PackedLayout pl = packed_layout(c);
@@ -968,6 +1030,7 @@ int backward_layout(const cnerf_cfg* c, int bprec, int cnt, bool have_act16, Bac
         L.a_g = take((size_t)L.n_mats * n * H * sizeof(float));
         L.a_go = take(n * 4 * sizeof(float));
     }
+    L.a_amax = 0;
     L.gmax = take((size_t)(L.n_mats + 2) * sizeof(uint32_t));
     L.scales = take((size_t)2 * (L.n_mats + 1) * sizeof(float));
     const size_t kmax = 32 * (size_t)(L.n_in > (int)NT ? L.n_in : (int)NT);
@@ -1019,6 +1082,110 @@ int cnerf_render_backward(const cnerf_cfg* cfg, int32_t bprec, int32_t cnt_max, 
     if (int rc = cnerf_merge_composite_backward(cfg, saved->coarse_rgb_sigma, saved->coarse_z, saved->fine_rgb_sigma, saved->fine_z,
                                                 cfg->noise_std != 0.0f ? rng->eps_final : nullptr, grad_pixels, grad_depth, gc, gf, stream_))
         return rc;
+
+    if (cfg->layer_kind[0] == CNERF_LAYER_PFILM) {
+        // ---- per-point FiLM family, half-precision backward: storing forward (field_pw16.hip), dry run -> scales, chain (chain_pw16.hip),
+        // one weight_grad16 reduction per matrix: dW_l = g_pre_l^T y_{l-1}, dWm2 rows = (g_fr_l | g_ph_l)^T m, dWm1 = g_mpre^T feat, head
+        const int Lc = cfg->L, n_slots = 3 * Lc + 2;
+        if (!P->map_w1 || !P->map_w2 || !P->w_final) return fail(CNERF_EINVAL, "render_backward: mapping network / head parameters are NULL");
+        if (!G->map_w1 || !G->map_b1 || !G->map_w2 || !G->map_b2 || !G->w_final || !G->b_final)
+            return fail(CNERF_EINVAL, "render_backward: per-point FiLM needs the mapping network's and the head's gradient buffers");
+        for (int l = 0; l < Lc; ++l)
+            if (!G->w[l] || !G->b[l]) return fail(CNERF_EINVAL, "render_backward: gradient buffers of layer %d are NULL", l);
+        const PwChainLayout cl = pw_chain_layout(cfg);
+        const char* base16 = (const char*)packed_bwd;
+        float* dwarg = (float*)(ws + L.dwarg);
+        float* cs = (float*)(ws + L.cs);
+        float* dwh = (float*)(ws + L.dwh);
+        float* csh = (float*)(ws + L.csh);
+        uint32_t* gmax = (uint32_t*)(ws + L.gmax);
+        float* scales = (float*)(ws + L.scales);
+        char* a_feat = ws + L.a_feat;
+        char* a_h = ws + L.a_h;
+        char* a_c = ws + L.a_c;
+        char* a_g = ws + L.a_g;
+        char* a_go = ws + L.a_go;
+        float* a_amax = (float*)(ws + L.a_amax);
+        if (hipError_t e = hipMemsetAsync(a_go, 0, (size_t)cnt_max * tpi * 2048, stream)) return hip_fail(e, "memset");
+        for (int pass = 0; pass < (hier ? 2 : 1); ++pass) {
+            const float* g_out = pass ? gf : gc;
+            const float* s_out = pass ? saved->fine_rgb_sigma : saved->coarse_rgb_sigma;
+            for (int b0 = 0; b0 < B; b0 += cnt_max) {
+                const int cnt = b0 + cnt_max <= B ? cnt_max : B - b0;
+                const long long T = (long long)cnt * tpi;
+                FieldArgs fa;
+                if (int rc = fill_field_args(fa, cfg, vols, grad_vols, packed, nullptr, nullptr, b0)) return rc;
+                if (!fa.lvl_grad[0]) return fail(CNERF_EINVAL, "render_backward: gradient volume is NULL");
+                set_points(fa, cnt, npi);
+                fa.cam2world = cam2world + (size_t)b0 * 16;
+                if (pass == 0) {
+                    fa.mode = FIELD_MODE_COARSE;
+                    fa.u_strat = rng->u_strat ? rng->u_strat + (size_t)b0 * npi : nullptr;
+                } else {
+                    fa.mode = FIELD_MODE_FINE;
+                    fa.fine_z = saved->fine_z + (size_t)b0 * npi;
+                }
+                {
+                    FieldArgs fs = fa;
+                    fs.rgb_sigma = (float*)a_g;      // (n,4) floats of head output nobody reads; the chain overwrites a_g entirely
+                    fs.z_out = nullptr;
+                    fs.act_points = (long long)cnt * npi;
+                    fs.act_feat = (float*)a_feat;
+                    fs.act_h = (float*)a_h;
+                    fs.act_c = (float*)a_c;
+                    fs.act_amax = a_amax;
+                    fs.act_tb16 = 1;
+                    if (hipError_t e = launch_field_pw3(fs, H, stream)) return hip_fail(e, "field kernel (fp16 activation store)");
+                }
+                fa.grad_out = g_out + (size_t)b0 * npi * 4;
+                fa.saved_out = s_out + (size_t)b0 * npi * 4;
+                if (hipError_t e = hipMemsetAsync(gmax, 0, (size_t)n_slots * sizeof(uint32_t), stream)) return hip_fail(e, "memset");
+                if (hipError_t e = launch_absmax_bits(fa.grad_out, (long long)cnt * npi * 4, gmax + n_slots - 1, stream)) return hip_fail(e, "absmax");
+                if (hipError_t e = launch_pow2_scales(gmax + n_slots - 1, 1, scales + 2 * (n_slots - 1), stream)) return hip_fail(e, "pow2_scales");
+                for (int m = 0; m < n_slots - 1; ++m)
+                    if (hipError_t e = launch_fill(scales + 2 * m, 1.0f, 2, stream)) return hip_fail(e, "fill");
+                const size_t slabH = (size_t)T * NT * 2048;            // bytes per (tiles, NT, 32, 32) slab
+                PwChainBuffers cb{base16, base16 + cl.head_off, (const float*)(base16 + cl.winv_off), (const float*)(base16 + cl.anorm_off), scales, a_c,
+                                  a_amax, a_h + (size_t)Lc * slabH, a_g, a_go, gmax, nullptr};
+                const long long groups = (long long)cnt * ((tpi + 3) / 4);
+                long long step = groups / 2048;                       // dry-run sampling: every 16th tile group once there are plenty
+                step = step < 1 ? 1 : (step > 16 ? 16 : step);
+                if (hipError_t e = launch_chain_pw16(fa, H, cb, 1, (int)step, stream)) return hip_fail(e, "chain_pw16 (dry run)");
+                if (hipError_t e = launch_pow2_scales(gmax, n_slots - 1, scales, stream)) return hip_fail(e, "pow2_scales");
+                cb.sat = saturated;
+                if (hipError_t e = launch_chain_pw16(fa, H, cb, 0, 1, stream)) return hip_fail(e, "chain_pw16");
+                // one reduction: G (n_rows of slab `slot`) against X (x_ct channel tiles), take k_real columns from column k0 on
+                auto reduce = [&](const void* Gs, int g_ct, int n_rows, int slot, const void* X, int x_ct, int k0, int k_real, float* dW, float* db) -> int {
+                    if (hipError_t e = hipMemsetAsync(dwarg, 0, (size_t)cnt * n_rows * 32 * x_ct * sizeof(float), stream)) return hip_fail(e, "memset");
+                    if (hipError_t e = hipMemsetAsync(cs, 0, (size_t)cnt * n_rows * sizeof(float), stream)) return hip_fail(e, "memset");
+                    if (int rc = cnerf_weight_grad16(cnt, tpi, n_rows, g_ct, x_ct, Gs, X, dwarg, cs, scales + 2 * slot + 1, stream_)) return rc;
+                    if (hipError_t e = launch_param_reduce(cnt, n_rows, 32 * x_ct, k_real, dwarg + k0, cs, nullptr, 0, nullptr, nullptr, dW, db, nullptr, nullptr, stream))
+                        return hip_fail(e, "param_reduce");
+                    return CNERF_OK;
+                };
+                const char* m16 = a_h + (size_t)Lc * slabH;
+                const size_t LH = (size_t)Lc * H;
+                for (int l = 0; l < Lc; ++l) {
+                    const char* g_pre = a_g + (size_t)(3 * l) * slabH;
+                    if (l == 0) {      // X = [feature | position]: the position's three columns
+                        if (int rc = reduce(g_pre, NT, H, 3 * l, a_feat, 2, 32, 3, G->w[0], G->b[0])) return rc;
+                    } else {
+                        if (int rc = reduce(g_pre, NT, H, 3 * l, a_h + (size_t)(l - 1) * slabH, NT, 0, H, G->w[l], G->b[l])) return rc;
+                    }
+                    if (int rc = reduce(g_pre + slabH, NT, H, 3 * l + 1, m16, 8, 0, 256, G->map_w2 + (size_t)l * H * 256, G->map_b2 + (size_t)l * H)) return rc;
+                    if (int rc = reduce(g_pre + 2 * slabH, NT, H, 3 * l + 2, m16, 8, 0, 256, G->map_w2 + (LH + (size_t)l * H) * 256, G->map_b2 + LH + (size_t)l * H))
+                        return rc;
+                }
+                if (int rc = reduce(a_g + (size_t)(3 * Lc) * slabH, 8, 256, 3 * Lc, a_feat, 2, 0, 32, G->map_w1, G->map_b1)) return rc;
+                if (hipError_t e = hipMemsetAsync(dwh, 0, (size_t)cnt * 4 * H * sizeof(float), stream)) return hip_fail(e, "memset");
+                if (hipError_t e = hipMemsetAsync(csh, 0, (size_t)cnt * 4 * sizeof(float), stream)) return hip_fail(e, "memset");
+                if (int rc = cnerf_weight_grad16(cnt, tpi, 4, 1, NT, a_go, a_h + (size_t)(Lc - 1) * slabH, dwh, csh, scales + 2 * (n_slots - 1) + 1, stream_)) return rc;
+                if (hipError_t e = launch_param_reduce(cnt, 4, H, H, dwh, csh, nullptr, 0, nullptr, nullptr, G->w_final, G->b_final, nullptr, nullptr, stream))
+                    return hip_fail(e, "param_reduce (head)");
+            }
+        }
+        return CNERF_OK;
+    }
 
     // the matrices in slab order (a residual block: fc1, fc2), their kinds and gradient buffers
     const float *Wm[2 * CNERF_MAX_LAYERS], *bm[2 * CNERF_MAX_LAYERS];

@@ -39,6 +39,7 @@ struct FieldArgs {
     float* act_h;            // (L,n,H) layer outputs sin(arg)
     float* act_c;            // (L,n,H) cos(arg)
     int act_tb16;            // 1: act_feat / act_h / act_c are fp16 buffers in the TB16 layout (bwd16.hpp), written by field_h3_kernel
+    float* act_amax;         // per-point FiLM family, act_tb16: (L, tiles * 32) largest |stored derivative| per layer and point (field_pw16.hip)
     // field_backward_kernel only
     const float* packed_t;   // transposed packed weights (cnerf_pack_field_transposed)
     const float* grad_out;   // (n,4) d loss / d rgb_sigma
@@ -200,5 +201,25 @@ hipError_t launch_chain16(const FieldArgs& f, int H, const void* units, const vo
                           void* g16, void* go16, unsigned int* gmax, unsigned int* sat, int nslab, int dry, int group_step, hipStream_t stream);
 hipError_t launch_weight_grad16(int cnt, long long tiles_per_image, int n_rows, int g_ct, int x_ct, const void* G, const void* X, float* dW,
                                 float* colsum, const float* inv_scale, hipStream_t stream);
+
+// chain_pw16.hip: half-precision gradient chain of the per-point FiLM family
+struct PwChainBuffers {
+    const void* units;        // transposed weight units (launch_pack_pw_chain)
+    const void* head_t;
+    const float* winv;        // [W_l^T: L (0 unused) | Wm2 pair of layer l: L | Wm1^T | head^T]
+    const float* anorm;       // [||W_l||_1: L (0 unused) | head]
+    const float* scales;      // {S, 1 / S} x (3 L + 2): per layer (g_pre, g_fr, g_ph), g_mpre, go
+    const void* cos16;        // 3 L COS16 slabs of the storing forward
+    const float* amax;        // (L, tiles * 32)
+    const void* m16;          // TB16 (tiles, 8, 32, 32)
+    void* g16;                // TB16: 3 L slabs (tiles, NT, 32, 32) then g_mpre (tiles, 8, 32, 32)
+    void* go16;
+    unsigned int* gmax;       // dry run: 3 L + 2 maxima
+    unsigned int* sat;
+};
+hipError_t launch_chain_pw16(const FieldArgs& f, int H, const PwChainBuffers& c, int dry, int group_step, hipStream_t stream);
+size_t pw_chain_units_bytes(int L, int H);
+hipError_t launch_pack_pw_chain(const cnerf_field_params* p, int L, int H, void* units, void* head_t, float* winv, float* anorm, uint32_t* wmax,
+                                hipStream_t stream);
 
 }  // namespace cnerf

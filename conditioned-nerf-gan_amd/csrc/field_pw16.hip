@@ -136,6 +136,53 @@ __device__ __forceinline__ void film_pair(const f32x16& q, const f32x16& ph, flo
     split_into(out2, r, v0, v1);
 }
 
+// Activation-storing forward of the half-precision backward (chain_pw16.hip): per layer and point, fp16:
+//   y = sin(arg)                     TB16 (bwd16.hpp): the X operand of the next layer's weight gradient
+//   cos(arg), cos(arg) f, cos(arg) 15 pre     COS16 fragment-major, three slabs per layer: d arg / d (phase, pre, raw frequency output)
+//                                    already multiplied into the cosine -- the chain is three multiplies per element
+// and per point the largest |stored derivative| of the layer (fp32): the chain scales its fp16 operands from it before they exist.
+struct PwStore {
+    _Float16* blk_h;       // y_l: the lane's row in channel tile 0 of the slab (+ 4 h)
+    _Float16* blk_c;       // cos: fragment (tile, t = 0, quad 0, lane) of slab 3 l
+    size_t cslab;          // fp16 elements per COS16 slab
+    float kf, kp;          // accf -> f, accp -> 15 pre
+    float amax;
+    float s[2], c[2], cf[2], cp[2];     // the first pair of a quad, held until the second arrives
+    bool live;
+};
+
+__device__ __forceinline__ void film_pair_store(const f32x16& fr, const f32x16& pre, const f32x16& ph, float c1, float c2, int t, int r, Split2* out2,
+                                                PwStore& st) {
+    float sn[2], cs[2], cf[2], cp[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const float q = fr[r + e] * pre[r + e];
+        const float u = __builtin_fmaf(q, c1, ph[r + e] * c2);
+        const float a = u - __builtin_rintf(u);
+        sn[e] = __builtin_amdgcn_sinf(a);
+        cs[e] = __builtin_amdgcn_cosf(a);
+        cf[e] = __builtin_amdgcn_fmed3f(cs[e] * (fr[r + e] * st.kf), -65504.0f, 65504.0f);
+        cp[e] = __builtin_amdgcn_fmed3f(cs[e] * (pre[r + e] * st.kp), -65504.0f, 65504.0f);
+        st.amax = fmaxf(st.amax, fmaxf(fabsf(cf[e]), fabsf(cp[e])));
+    }
+    if ((r & 2) == 0) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            st.s[e] = sn[e];
+            st.c[e] = cs[e];
+            st.cf[e] = cf[e];
+            st.cp[e] = cp[e];
+        }
+    } else if (st.live) {
+        *reinterpret_cast<u32x2_*>(st.blk_h + t * 1024 + 8 * (r >> 2)) = u32x2_{pk_f16(st.s[0], st.s[1]), pk_f16(sn[0], sn[1])};
+        _Float16* cq = st.blk_c + (size_t)(t * 4 + (r >> 2)) * 256;
+        *reinterpret_cast<u32x2_*>(cq) = u32x2_{pk_f16(st.c[0], st.c[1]), pk_f16(cs[0], cs[1])};
+        *reinterpret_cast<u32x2_*>(cq + st.cslab) = u32x2_{pk_f16(st.cf[0], st.cf[1]), pk_f16(cf[0], cf[1])};
+        *reinterpret_cast<u32x2_*>(cq + 2 * st.cslab) = u32x2_{pk_f16(st.cp[0], st.cp[1]), pk_f16(cp[0], cp[1])};
+    }
+    split_into(out2, r, sn[0], sn[1]);
+}
+
 struct TilePoint {
     int b;
     long long nn;      // point inside the image (clamped to the last one for idle waves / padded lanes)
@@ -155,8 +202,10 @@ struct FirstLayer { static constexpr bool value = true; };
 struct LaterLayer { static constexpr bool value = false; };
 
 // Constants in LDS (a.bias, written by pw16_consts_kernel):  bm1 S (256) | per layer: b_l S_pre, (bm2 + 2) S_f, bm2 S_ph (3 H) | head bias (4)
-// | 1 / S of Wm1, 1 / S of the head, per layer c1, c2 | the raw 1 / S and max|W| slots of the packing (unused here)
-template <int NT>
+// | 1 / S of Wm1, 1 / S of the head, per layer c1, c2, 15 / S_f, 15 / S_pre | the raw 1 / S and max|W| slots of the packing (unused here)
+// STORE: act_feat = TB16 (tiles, 2, 32, 32): the looked-up feature, the position; act_h = L slabs y_l (tiles, NT, 32, 32) then m (tiles, 8,
+// 32, 32); act_c = 3 L COS16 slabs; act_amax = (L, tiles * 32) floats.
+template <int NT, bool STORE>
 __global__ __launch_bounds__(256) void field_pw16_kernel(FieldArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int H = NT * 32;
@@ -229,6 +278,15 @@ __global__ __launch_bounds__(256) void field_pw16_kernel(FieldArgs a) {
         tile_point(a, tp.b, tp.nn, tp.valid, h, true, px, py, pz);
         InputTile it;
         input_tile_issue_volume(a, tp.b, 0, px, py, pz, h, it);
+        // activation store: TB16 tile T = image * tiles_per_image + tile in image; an idle wave (a tile past the image's last) stores nothing
+        const long long tile_in_image = (g - (long long)tp.b * G) * 4 + wave;
+        const long long tile_T = (long long)tp.b * a.tiles_per_image + tile_in_image;
+        const size_t slab16 = (size_t)a.total_tiles * NT * 1024;
+        PwStore st;
+        st.live = STORE && tile_in_image < a.tiles_per_image;
+        st.cslab = slab16;
+        st.blk_h = STORE ? reinterpret_cast<_Float16*>(a.act_h) + ((size_t)tile_T * NT * 32 + j) * 32 + 4 * h : nullptr;
+        st.blk_c = STORE ? reinterpret_cast<_Float16*>(a.act_c) + ((size_t)tile_T * NT * 256 + lane) * 4 : nullptr;
 
         // ---- mapping hidden layer: m = LeakyReLU_0.2(Wm1 feat + bm1), 8 output tiles ----------------------------------------
         Split2 m[KCM];
@@ -238,6 +296,16 @@ __global__ __launch_bounds__(256) void field_pw16_kernel(FieldArgs a) {
             float fv[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) fv[r] = feat[r];
+            if (STORE && st.live) {          // X operand of dWm1: the looked-up feature, clamped to fp16's range like the MFMA operand
+                _Float16* fo = reinterpret_cast<_Float16*>(a.act_feat) + (((size_t)tile_T * 2 + 0) * 32 + j) * 32 + 4 * h;
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    float c4[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) c4[e] = __builtin_amdgcn_fmed3f(fv[4 * gq + e], -65504.0f, 65504.0f);
+                    *reinterpret_cast<u32x2_*>(fo + 8 * gq) = u32x2_{pk_f16(c4[0], c4[1]), pk_f16(c4[2], c4[3])};
+                }
+            }
             Split2 f2[2];
             f2[0] = split8_clamped(fv);
             f2[1] = split8_clamped(fv + 8);
@@ -256,6 +324,15 @@ __global__ __launch_bounds__(256) void field_pw16_kernel(FieldArgs a) {
                     v0 = __builtin_amdgcn_fmed3f(v0, -65504.0f, 65504.0f);      // (unbounded, unlike sine outputs)
                     v1 = __builtin_amdgcn_fmed3f(v1, -65504.0f, 65504.0f);
                     split_into(&m[2 * t], r, v0, v1);
+                    if (STORE) {                                                 // X operand of dWm2, and the sign for LeakyReLU'
+                        if ((r & 2) == 0) {
+                            st.s[0] = v0;
+                            st.s[1] = v1;
+                        } else if (st.live) {
+                            _Float16* mo = reinterpret_cast<_Float16*>(a.act_h) + (size_t)a.L * slab16 + (((size_t)tile_T * 8 + t) * 32 + j) * 32 + 4 * h;
+                            *reinterpret_cast<u32x2_*>(mo + 8 * (r >> 2)) = u32x2_{pk_f16(st.s[0], st.s[1]), pk_f16(v0, v1)};
+                        }
+                    }
                 }
         }
         // ---- layer 0 reads the world position: pre_0 of all NT output tiles from one unit -----------------------------------------
@@ -270,6 +347,12 @@ __global__ __launch_bounds__(256) void field_pw16_kernel(FieldArgs a) {
                 fv[1] = py;
                 fv[2] = pz;
             }
+            if (STORE && st.live) {          // X operand of dW_0: the position in channels 0..2 of a 32-channel tile, zeros behind
+                _Float16* fo = reinterpret_cast<_Float16*>(a.act_feat) + (((size_t)tile_T * 2 + 1) * 32 + j) * 32 + 4 * h;
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq)
+                    *reinterpret_cast<u32x2_*>(fo + 8 * gq) = gq == 0 ? u32x2_{pk_f16(fv[0], fv[1]), pk_f16(fv[2], 0.0f)} : u32x2_{0u, 0u};
+            }
             Split2 f2[2];
             f2[0] = split8_clamped(fv);
 #pragma unroll
@@ -283,13 +366,21 @@ __global__ __launch_bounds__(256) void field_pw16_kernel(FieldArgs a) {
         auto layer = [&](const Split2* in, Split2* out, auto first_tag, int l) {
             constexpr bool FIRST = decltype(first_tag)::value;
             const float* ci = c_lay + (size_t)l * 3 * H;              // starting values: pre, fr, ph
-            const float c1 = c_scal[2 + 2 * l], c2 = c_scal[3 + 2 * l];
-            f32x16 q_prev, ph_prev;
+            const float c1 = c_scal[2 + 4 * l], c2 = c_scal[3 + 4 * l];
+            if (STORE) {
+                st.kf = c_scal[4 + 4 * l];
+                st.kp = c_scal[5 + 4 * l];
+                st.amax = 1.0f;                        // |cos| <= 1
+            }
+            f32x16 q_prev, ph_prev, pre_prev;          // (STORE: q_prev holds accf, not accf accp)
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 f32x16 fr = load_chan16(ci + H, t, h);
                 fr = tile_kc<KCM, 6>(unit_begin(), m, fr, lane, [&](int c) {
-                    if (t > 0 && (c & 1)) film_pair(q_prev, ph_prev, c1, c2, c - 1, &out[2 * (t - 1)]);
+                    if (t > 0 && (c & 1)) {
+                        if constexpr (STORE) film_pair_store(q_prev, pre_prev, ph_prev, c1, c2, t - 1, c - 1, &out[2 * (t - 1)], st);
+                        else film_pair(q_prev, ph_prev, c1, c2, c - 1, &out[2 * (t - 1)]);
+                    }
                 });
                 f32x16 pre;
                 if constexpr (FIRST) {
@@ -299,13 +390,28 @@ __global__ __launch_bounds__(256) void field_pw16_kernel(FieldArgs a) {
                     pre = tile_kc<KCH, 0>(unit_begin(), in, pre, lane, [](int) {});
                 }
                 f32x16 ph = load_chan16(ci + 2 * H, t, h);
-                f32x16 q;
-                ph = tile_kc<KCM, 1>(unit_begin(), m, ph, lane, [&](int c) { q[c] = fr[c] * pre[c]; });
-                q_prev = q;
+                if constexpr (STORE) {
+                    ph = tile_kc<KCM, 0>(unit_begin(), m, ph, lane, [](int) {});
+                    q_prev = fr;
+                    pre_prev = pre;
+                } else {
+                    f32x16 q;
+                    ph = tile_kc<KCM, 1>(unit_begin(), m, ph, lane, [&](int c) { q[c] = fr[c] * pre[c]; });
+                    q_prev = q;
+                }
                 ph_prev = ph;
             }
 #pragma unroll
-            for (int r = 0; r < 16; r += 2) film_pair(q_prev, ph_prev, c1, c2, r, &out[2 * (NT - 1)]);
+            for (int r = 0; r < 16; r += 2) {
+                if constexpr (STORE) film_pair_store(q_prev, pre_prev, ph_prev, c1, c2, NT - 1, r, &out[2 * (NT - 1)], st);
+                else film_pair(q_prev, ph_prev, c1, c2, r, &out[2 * (NT - 1)]);
+            }
+            if (STORE) {
+                const float am = fmaxf(st.amax, __shfl_xor(st.amax, 32, WAVE));       // the two lane halves hold the two halves of a point's channels
+                if (st.live && h == 0) a.act_amax[((size_t)l * a.total_tiles + tile_T) * 32 + j] = am;
+                st.blk_h += slab16;
+                st.blk_c += 3 * slab16;
+            }
         };
         layer(x, x, FirstLayer{}, 0);
         for (int l = 1; l < L; ++l) {
@@ -341,28 +447,30 @@ __global__ __launch_bounds__(256) void field_pw16_kernel(FieldArgs a) {
 
 constexpr size_t LDS_LIMIT = 160 * 1024;
 
-template <int NT>
+template <int NT, bool STORE>
 static hipError_t launch_inst(const FieldArgs& a, hipStream_t stream) {
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) != hipSuccess) dev = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
     const size_t lds_bytes = 2 * (size_t)KCM * PARTS * 1024 + (size_t)a.bias_floats * 4;
     if (lds_bytes > LDS_LIMIT) return hipErrorInvalidValue;
-    if (hipError_t e = hipFuncSetAttribute((const void*)field_pw16_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT)) return e;
+    if (hipError_t e = hipFuncSetAttribute((const void*)field_pw16_kernel<NT, STORE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT)) return e;
     const long long want = (a.total_tiles / a.tiles_per_image) * ((a.tiles_per_image + 3) / 4);
     int blocks = (int)(want < cus ? want : cus);        // one block of four waves per CU (512 registers per wave)
     if (blocks < 8) blocks = 8;
     blocks = (blocks + 7) / 8 * 8;
-    hipLaunchKernelGGL((field_pw16_kernel<NT>), dim3(blocks), dim3(256), lds_bytes, stream, a);
+    hipLaunchKernelGGL((field_pw16_kernel<NT, STORE>), dim3(blocks), dim3(256), lds_bytes, stream, a);
     return hipGetLastError();
 }
 
 static hipError_t field_impl(const FieldArgs& a, int H, hipStream_t stream) {
-    if (a.n_in != 1 || a.in_level[0] < 0 || a.L < 1 || a.act_h) return hipErrorInvalidValue;      // one 32-channel volume tile, plain forward
+    if (a.n_in != 1 || a.in_level[0] < 0 || a.L < 1) return hipErrorInvalidValue;      // one 32-channel volume tile
+    const bool store = a.act_h != nullptr;             // activation-storing forward of the half-precision backward (fp16 tile blocks)
+    if (store && (!a.act_tb16 || !a.act_feat || !a.act_c || !a.act_amax)) return hipErrorInvalidValue;
     switch (H / 32) {
-        case 2: return launch_inst<2>(a, stream);
-        case 4: return launch_inst<4>(a, stream);
-        case 8: return launch_inst<8>(a, stream);
+        case 2: return store ? launch_inst<2, true>(a, stream) : launch_inst<2, false>(a, stream);
+        case 4: return store ? launch_inst<4, true>(a, stream) : launch_inst<4, false>(a, stream);
+        case 8: return store ? launch_inst<8, true>(a, stream) : launch_inst<8, false>(a, stream);
         default: return hipErrorInvalidValue;
     }
 }
@@ -390,7 +498,7 @@ struct PwConstArgs {
 
 __global__ void pw16_consts_kernel(PwConstArgs a) {
     const int LH3 = 3 * a.L * a.H;
-    const int n_scal = (2 + 2 * a.L + 3) / 4 * 4;
+    const int n_scal = (2 + 4 * a.L + 3) / 4 * 4;
     const int total = 256 + LH3 + 4 + n_scal;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         float v = 0.0f;
@@ -409,10 +517,12 @@ __global__ void pw16_consts_kernel(PwConstArgs a) {
             const double inv_2pi = 0.15915494309189533577;
             if (s == 0) v = a.inv_s[0];
             else if (s == 1) v = a.inv_s[3 * a.L + 1];
-            else if (s < 2 + 2 * a.L) {
-                const int l = (s - 2) >> 1;
-                if ((s & 1) == 0) v = (float)(15.0 * (double)a.inv_s[2 + 3 * l] * (double)a.inv_s[1 + 3 * l] * inv_2pi);
-                else v = (float)((double)a.inv_s[3 + 3 * l] * inv_2pi);
+            else if (s < 2 + 4 * a.L) {
+                const int l = (s - 2) >> 2, w = (s - 2) & 3;
+                if (w == 0) v = (float)(15.0 * (double)a.inv_s[2 + 3 * l] * (double)a.inv_s[1 + 3 * l] * inv_2pi);      // c1
+                else if (w == 1) v = (float)((double)a.inv_s[3 + 3 * l] * inv_2pi);                                      // c2
+                else if (w == 2) v = 15.0f * a.inv_s[2 + 3 * l];                                                         // accf -> f
+                else v = 15.0f * a.inv_s[1 + 3 * l];                                                                     // accp -> 15 pre
             }
         }
         a.out[i] = v;

@@ -176,8 +176,9 @@ class PointwiseFiLMLayer(_LinearSine):
 class TALLSIREN(FieldNetwork):
     """pi-GAN style field (siren.py:232-331): input = world xyz, eight FiLM layers whose frequencies / phases come per
     POINT from a mapping MLP of the looked-up feature (z is the bare feature volume, z_dim = its channel count).
-    Parameters, names and initialisation mirror the reference so its checkpoints load.  fp32 only (forward: field_pw_kernel;
-    backward: storing forward + field_pw_backward_kernel, ops._pfilm_backward)."""
+    Parameters, names and initialisation mirror the reference so its checkpoints load.  Forward: field_pw_kernel (fp32) or
+    field_pw16_kernel (fp16x3 / fp16); backward: storing forward + field_pw_backward_kernel + library GEMMs (fp32,
+    ops._pfilm_backward) or chain_pw16_kernel + weight_grad16 behind cnerf_render_backward (backward_precision "fp16")."""
     variant = "TALLSIREN"
     spec = FieldSpec(("pfilm",) * 8, 25, False, False, False, "xyz")
 

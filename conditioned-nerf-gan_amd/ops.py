@@ -414,13 +414,11 @@ def _pfilm_backward(net, o, cfg, levels, cam2world, rng, saved, gc, gf):
 
 def backward_precision_of(net):
     """Arithmetic of the backward's gradient GEMMs: `net.backward_precision` = "fp32" (exact fp32 MFMA chain and weight
-    gradients, the default) or "fp16" (fp16 operands, fp32 sums: the reference's own training numerics, utils.py:643 autocast);
-    "fp16" covers FiLM / plain-sine / residual-block networks, the per-point FiLM family runs the fp32 path."""
+    gradients, the default) or "fp16" (fp16 operands, fp32 sums: the reference's own training numerics, utils.py:643 autocast):
+    bwd16.hip for FiLM / plain-sine / residual-block networks, chain_pw16.hip for the per-point FiLM family."""
     p = getattr(net, "backward_precision", "fp32")
     if p not in ("fp32", "fp16"):
         raise L.CnerfError(f"unknown backward precision {p!r}")
-    if p == "fp16" and any(k not in ("film", "sine", "res") for k in net.spec.layers):
-        return "fp32"
     return p
 
 
@@ -470,9 +468,11 @@ def resident_act16(net, levels, B, R, S, hier, dev):
 
 
 def _field_param_grads_struct(net, grads):
-    """cnerf_field_param_grads over the flat tensor list `grads` (same order as net.field_params(), no mapping MLP)."""
+    """cnerf_field_param_grads over the flat tensor list `grads` (same order as net.field_params(): mapping MLP first for the per-point family)."""
     gp = L.FieldParamGrads()
     it = iter(grads)
+    if net.spec.input == "xyz":
+        gp.map_w1, gp.map_b1, gp.map_w2, gp.map_b2 = (next(it).data_ptr() for _ in range(4))
     for i, kind in enumerate(net.spec.layers):
         gp.w[i], gp.b[i] = next(it).data_ptr(), next(it).data_ptr()
         if kind == "res":
@@ -508,8 +508,8 @@ LAST_SATURATED = None          # device int32 tensor of the most recent fp16 bac
 
 def render_backward(net, o, levels, freq, phase, cam2world, rng, saved, grad_pixels, grad_depth, act16=None):
     """Gradients of one render w.r.t. (channel-last feature volumes, freq, phase, [field parameters]): ONE call into the library
-    (cnerf_render_backward) for the FiLM / plain-sine / residual families; the per-point FiLM family finishes its mapping-MLP
-    gradients with library GEMMs (_pfilm_backward)."""
+    (cnerf_render_backward); the exact fp32 backward of the per-point FiLM family finishes its mapping-MLP gradients with library
+    GEMMs (_pfilm_backward)."""
     global LAST_SATURATED
     B, R, S, hier = o["B"], o["R"], o["S"], o["hier"]
     dev = cam2world.device
@@ -521,7 +521,7 @@ def render_backward(net, o, levels, freq, phase, cam2world, rng, saved, grad_pix
     c_rs, c_z, f_rs, f_z = saved[:4]
     grad_pixels = _f32(grad_pixels)
     grad_depth = _f32(grad_depth) if grad_depth is not None else None
-    if net.spec.layers[0] == "pfilm":      # (fp32 chain: the activation-storing re-run and its packed weights are the fp32 kernel's)
+    if net.spec.layers[0] == "pfilm" and bprec == "fp32":      # (fp32 chain: the activation-storing re-run and its packed weights are the fp32 kernel's)
         cfg = make_cfg(net, B, levels, R, S, o["fov"], o["ray_start"], o["ray_end"], o["noise_std"], hier, o["white_back"], o["last_back"],
                        o["clamp_mode"], precision="fp32", philox=rng.get("philox"), drop=drop_of(rng))
         gc = torch.empty_like(c_rs)
@@ -592,7 +592,7 @@ class RenderFunction(torch.autograd.Function):
         need_grad = any(ctx.needs_input_grad)   # (grad mode is always off inside Function.forward)
         keys = SAVED_KEYS + (("coarse_points", "fine_points") if net.spec.layers[0] == "pfilm" else ())   # see _pfilm_backward
         act16 = None
-        if need_grad and backward_precision_of(net) == "fp16" and precision_of(net) in ("fp16x3", "fp16"):
+        if need_grad and backward_precision_of(net) == "fp16" and precision_of(net) in ("fp16x3", "fp16") and net.spec.layers[0] != "pfilm":
             act16 = resident_act16(net, levels, cam2world.shape[0], o["R"], o["S"], o["hier"], cam2world.device)
         pixels, depth, aux = render_forward(net, levels, fr, ph, cam2world, o["R"], o["fov"], o["ray_start"], o["ray_end"],
                                             o["S"], o["hier"], o["clamp_mode"], o["noise_std"], o["white_back"],

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define CNERF_ABI_VERSION 6
+#define CNERF_ABI_VERSION 7
 
 #define CNERF_OK 0
 #define CNERF_EINVAL (-22)  /* bad argument / unsupported shape (message via cnerf_last_error) */
@@ -360,8 +360,9 @@ int cnerf_field_backward16(const cnerf_cfg* cfg, uint32_t mode, int32_t group_st
  *
  *   backward_precision  CNERF_PREC_FP32: exact fp32 chain and weight reductions (re-run in cfg->precision);
  *                       CNERF_PREC_FP16: fp16 operands, fp32 sums (cnerf_field_backward16 / cnerf_weight_grad16; cfg->precision must
- *                       be CNERF_PREC_FP16X3).  Per-point FiLM networks: CNERF_ENOSYS (their mapping-MLP reductions are library GEMMs on
- *                       the host: cnerf_field_backward + cnerf_weight_grad + cnerf_scatter_features).
+ *                       be CNERF_PREC_FP16X3).  Per-point FiLM networks (ABI v7): CNERF_PREC_FP16 runs here (csrc/chain_pw16.hip; grads->map_*
+ *                       receive the mapping network's gradients); CNERF_PREC_FP32 answers CNERF_ENOSYS -- the exact path finishes its
+ *                       mapping-MLP reductions with library GEMMs on the host (cnerf_field_backward + cnerf_weight_grad + cnerf_scatter_features).
  *   params              the raw parameters (dfreq needs W_l and b_l);  packed: cnerf_pack_field in cfg->precision;
  *   packed_bwd          cnerf_pack_field_transposed (fp32 backward) or cnerf_pack_field_chain16 (fp16 backward).
  *   saved               the forward's coarse / fine rgb_sigma and z (cnerf_aux of that call; fine_* NULL when not hierarchical).
@@ -382,6 +383,11 @@ typedef struct cnerf_field_param_grads {
     float* b2[CNERF_MAX_LAYERS];
     float* w_final;
     float* b_final;
+    /* per-point FiLM family only (ABI v7): gradients of siren.mapping_network.network.{0,2} */
+    float* map_w1; /* [256][C]      */
+    float* map_b1; /* [256]         */
+    float* map_w2; /* [2*L*H][256]  */
+    float* map_b2; /* [2*L*H]       */
 } cnerf_field_param_grads;
 
 typedef struct cnerf_saved {

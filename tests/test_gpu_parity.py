@@ -461,7 +461,7 @@ def test_backward_split_precision(golden, dev, name):
 
 
 HALF_BACKWARD_FIXTURES = [n for n in GRAD_FIXTURES if n.startswith(("short_fg", "tall_fg", "double_fg", "single_dg", "short_f_", "tall_dgx", "short_pyrmd",
-                                                                     "short_fres", "tall_dres"))]
+                                                                     "short_fres", "tall_dres", "tallsiren"))]
 
 
 def rel_l2(a, b):
@@ -1018,8 +1018,10 @@ def test_backward_ragged_shapes_vs_oracle_autograd(dev, shape, backward_precisio
 @pytest.mark.parametrize("shape", [dict(B=2, R=5, S=7, V=9, H=64), dict(B=1, R=3, S=33, V=6, H=128), dict(B=3, R=4, S=9, V=5, H=256)])
 def test_backward_per_point_film_vs_oracle_autograd(dev, shape):
     """The same for TALLSIREN (per-point FiLM, siren.py:232-331): storing forward + gradient chain kernels, weight-gradient
-    reductions and the mapping network's GEMMs against autograd through the CPU oracle, at all three widths and ragged tiles."""
-    _ragged_backward_case(dev, shape, "TALLSIREN", "fp32")
+    reductions and the mapping network's GEMMs against autograd through the CPU oracle, at all three widths and ragged tiles --
+    the exact fp32 path (field_pw_backward_kernel + library GEMMs) and the half-precision one (field_pw16 storing forward,
+    chain_pw16_kernel, weight_grad16 behind cnerf_render_backward)."""
+    _ragged_backward_case(dev, shape, "TALLSIREN", ("fp32", "fp16"))
 
 
 @pytest.mark.parametrize("variant", ["TALLSIREN_dRes", "SHORTSIREN_FRes", "TALLSIREN_dResLong"])
