@@ -106,6 +106,9 @@ __device__ __forceinline__ void epi_element(const f32x16& z, const f16x4 (*cq)[4
     }
 }
 
+struct RescaleYes { static constexpr bool value = true; };
+struct RescaleNo { static constexpr bool value = false; };
+
 template <int NT, bool DRY>
 __global__ __launch_bounds__(256) void chain_pw16_kernel(Args A) {
     extern __shared__ __attribute__((aligned(16))) char smem_p[];
@@ -114,8 +117,9 @@ __global__ __launch_bounds__(256) void chain_pw16_kernel(Args A) {
     constexpr int P_M = 32, P_Y = KCH, P_W1 = 16;       // 1-KiB pieces per unit kind
     constexpr int SLOT_FR = 32 * 64;                    // fragments per LDS slot
     constexpr int CD = 2;                               // prefetch distance of the derivative rows, in tiles
-    f16x8* lds_units = reinterpret_cast<f16x8*>(smem_p);                       // 2 slots
-    f16x8* lds_head = lds_units + 2 * SLOT_FR;                                  // NT * 64 fragments
+    constexpr int SLOTS = 3;                            // weight units in LDS: one being read, two being copied
+    f16x8* lds_units = reinterpret_cast<f16x8*>(smem_p);
+    f16x8* lds_head = lds_units + SLOTS * SLOT_FR;                              // NT * 64 fragments
     float* s_g = reinterpret_cast<float*>(lds_head + NT * 64);                  // [4][32][33] scatter transpose
     int* s_base = reinterpret_cast<int*>(s_g + 4 * 32 * 33);                    // [4][32][8]
     float* s_w = reinterpret_cast<float*>(s_base + 4 * 32 * 8);                 // [4][32][8]
@@ -159,22 +163,26 @@ __global__ __launch_bounds__(256) void chain_pw16_kernel(Args A) {
             dma_k = 0;
             dma_src = A.units;
         }
-        dma_slot ^= 1;
+        dma_slot = dma_slot == SLOTS - 1 ? 0 : dma_slot + 1;
     };
-    // every wave, at the start of every unit: its share of the unit's copy (requested at the previous unit_begin) has landed.  vmcnt
-    // retires in order: YOUNGER = a lower bound, known at the call site, on the vector-memory operations issued since that request (the
-    // prefetch of derivative rows: 12 loads; the gradient stores of an epilogue: 12) -- they may stay in flight.
+    // Every wave, at the start of every unit: its share of the unit's copy has landed.  The copy of unit k is requested two units earlier
+    // (three slots); vmcnt retires in order and the wait is written out: at most `younger` operations may stay in flight,
+    // a lower bound, known at the call site, on what the wave has issued since that request -- the copy instructions of unit k + 1
+    // (>= PWMIN), the prefetch of derivative rows behind an epilogue (12 loads; every wave issues it) -- so that the gradient stores and
+    // the prefetch stay in flight across the barrier, which orders LDS only.
+    constexpr int PWMIN = (P_Y < P_W1 ? P_Y : P_W1) / 4;
     auto unit_begin = [&](int younger) -> const f16x8* {
-        if (younger >= 12) wait_vmcnt<12>();
-        else wait_vmcnt<0>();
+        if (younger >= 12) wait_vmcnt<12 + PWMIN>();
+        else wait_vmcnt<PWMIN>();
         lds_only_barrier();
         dma_next();
         const f16x8* u = lds_units + use_slot * SLOT_FR;
-        use_slot ^= 1;
+        use_slot = use_slot == SLOTS - 1 ? 0 : use_slot + 1;
         return u;
     };
 
     for (int i = threadIdx.x; i < NT * 64; i += 256) lds_head[i] = A.head_t[i];
+    dma_next();
     dma_next();
     const float* winvY = A.winv;
     const float* winvM = A.winv + L;
@@ -253,14 +261,22 @@ __global__ __launch_bounds__(256) void chain_pw16_kernel(Args A) {
         Epi st;
         st.live = live;
         st.slab = slab16;
-        // M(t): gm[ot] += sum over the 4 k-chunks (2 of g_fr, 2 of g_ph) of unit fragment (cc, ot) x operand cc; `ride(i)` runs behind MFMA i
-        auto m_product = [&](const f16x8* unit, const u32x4* ffr, const u32x4* fph, auto ride) {
+        // M(t): gm[ot] += sum over the 4 k-chunks (2 of g_fr, 2 of g_ph) of unit fragment (cc, ot) x operand cc; `ride(i)` runs behind MFMA i.
+        // RESCALE (the first M unit of a stage): each accumulator tile moves to the stage's units right before its first product --
+        // tile by tile, because accumulators live in the accumulation registers and vector instructions work on copies: all 128 values
+        // at once (a loop over gm at the stage boundary) spilled 300 registers
+        auto m_product = [&](const f16x8* unit, const u32x4* ffr, const u32x4* fph, auto rescale_tag, float rho, auto ride) {
+            constexpr bool RESCALE = decltype(rescale_tag)::value;
             f16x8 ring[2] = {unit[lane], unit[64 + lane]};
 #pragma unroll
             for (int i = 0; i < 32; ++i) {
                 const int cc = i >> 3, ot = i & 7;
                 const f16x8 aw = ring[i & 1];
                 if (i + 2 < 32) ring[i & 1] = unit[(i + 2) * 64 + lane];
+                if (RESCALE && i < 8) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) gm[ot][r] *= rho;
+                }
                 const u32x4 bq = cc < 2 ? ffr[cc] : fph[cc - 2];
                 gm[ot] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aw, __builtin_bit_cast(f16x8, bq), gm[ot], 0, 0, 0);
                 ride(i);
@@ -283,14 +299,9 @@ __global__ __launch_bounds__(256) void chain_pw16_kernel(Args A) {
             st.USph = U * A.scales[2 * (3 * lam + 2)];
             st.mpre = st.mfr = st.mph = 0.0f;
             st.gdst = A.g16 + (size_t)(3 * lam) * slab16 + row16 + 4 * h;
-            if (!first) {                                // g_m moves to this stage's units: both factors are powers of two
-                const float rho = (winvM[lam + 1] / winvM[lam]) * (T / T_prev);
-#pragma unroll
-                for (int ot = 0; ot < 8; ++ot)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) gm[ot][r] *= rho;
-            }
-            u32x4 fcur_fr[2], fcur_ph[2], fnew_fr[2], fnew_ph[2];
+            // g_m moves to this stage's units (both factors are powers of two): applied inside the stage's first M unit
+            const float rho = first ? 1.0f : (winvM[lam + 1] / winvM[lam]) * (T / T_prev);
+            u32x4 ffr[2][2], fph[2][2];                   // g_fr / g_ph operands of a tile (2 k-chunks each), by tile parity
             f32x16 z;
 #pragma unroll
             for (int t = 0; t <= NT; ++t) {
@@ -305,8 +316,9 @@ __global__ __launch_bounds__(256) void chain_pw16_kernel(Args A) {
                         z = __builtin_amdgcn_mfma_f32_32x32x16_f16(aw, __builtin_bit_cast(f16x8, bl), z, 0, 0, 0);
                         z = __builtin_amdgcn_mfma_f32_32x32x16_f16(aw, __builtin_bit_cast(f16x8, bh), z, 0, 0, 0);
                     } else {
-                        // since the request of this unit's copy (t >= 1): the prefetch behind epilogue(t-1), 12 loads (+ its 12 stores)
-                        const f16x8* unit = unit_begin(t >= 1 ? 12 : 0) + lane;
+                        // since the request of this unit's copy (two unit_begins ago) every wave has issued a prefetch: behind epilogue(t-1)
+                        // (t >= 1), behind the last epilogue of the stage above (t = 0)
+                        const f16x8* unit = unit_begin(12) + lane;
                         f16x8 ring[2] = {unit[0], unit[64]};
 #pragma unroll
                         for (int c = 0; c < KCH; ++c) {
@@ -319,25 +331,18 @@ __global__ __launch_bounds__(256) void chain_pw16_kernel(Args A) {
                 // ---- epilogue(t), under the MFMAs of M(t-1) ------------------------------------------------------------------------
                 if (t == 0) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) epi_element<DRY>(z, cosr[0], 0, r, st, frag_out, fnew_fr, fnew_ph);
+                    for (int r = 0; r < 16; ++r) epi_element<DRY>(z, cosr[0], 0, r, st, frag_out, ffr[0], fph[0]);
                     prefetch_after(lam, 0);
                 } else {
-                    // since the request of this unit's copy: nothing behind a Y unit (its phase is MFMAs only); without one (stage L-1,
-                    // and the last M of every stage) the prefetch behind the previous epilogue -- or, for a tile's first unit, its first rows
-                    const f16x8* unit = unit_begin((first || t == NT) ? 12 : 0);
-                    if (t < NT) {
-                        m_product(unit, fcur_fr, fcur_ph, [&](int i) {
-                            if (i & 1) epi_element<DRY>(z, cosr[t % CD], t, i >> 1, st, frag_out, fnew_fr, fnew_ph);
-                        });
-                        prefetch_after(lam, t);
-                    } else {
-                        m_product(unit, fcur_fr, fcur_ph, [](int) {});
-                    }
-                }
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    fcur_fr[q] = fnew_fr[q];
-                    fcur_ph[q] = fnew_ph[q];
+                    // since the request of this unit's copy (two unit_begins ago): t >= 2, or any t without Y units (stage L-1): the
+                    // prefetch behind epilogue(t-1); t = 1 behind Y units: the one behind epilogue(0)
+                    const f16x8* unit = unit_begin(12);
+                    auto ride = [&](int i) {
+                        if (t < NT && (i & 1)) epi_element<DRY>(z, cosr[t % CD], t, i >> 1, st, frag_out, ffr[t & 1], fph[t & 1]);
+                    };
+                    if (t == 1) m_product(unit, ffr[0], fph[0], RescaleYes{}, rho, ride);
+                    else m_product(unit, ffr[(t - 1) & 1], fph[(t - 1) & 1], RescaleNo{}, 1.0f, ride);
+                    if (t < NT) prefetch_after(lam, t);
                 }
             }
             // ---- end of the stage: maxima, operand bound of the next -------------------------------------------------------------------
@@ -362,21 +367,26 @@ __global__ __launch_bounds__(256) void chain_pw16_kernel(Args A) {
         }
 
         // ---- mapping network: g_mpre = g_m LeakyReLU'(m), g_feat = Wm1^T g_mpre --------------------------------------------------------
+        // (two passes over the 8 accumulator tiles, each tile by tile: the point's largest |g_mpre| must be known before the operand
+        // scale, and holding all 128 products in vector registers meanwhile is what spills)
         const float Um = winvM[0] / T_prev;                                              // accumulator -> true g_m
         const _Float16* mrow = A.m16 + ((size_t)tile_T * 8 * 32 + j) * 32 + 4 * h;
+        auto mpre_of = [&](int ot, int gq, f32x4& v) {
+            const f16x4 mq = *reinterpret_cast<const f16x4*>(mrow + ot * 1024 + 8 * gq);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = gm[ot][4 * gq + e] * Um * ((float)mq[e] > 0.0f ? 1.0f : 0.2f);
+        };
         float mx = 0.0f;
 #pragma unroll
-        for (int ot = 0; ot < 8; ++ot)
+        for (int ot = 0; ot < 8; ++ot) {
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
-                const f16x4 mq = *reinterpret_cast<const f16x4*>(mrow + ot * 1024 + 8 * gq);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float v = gm[ot][4 * gq + e] * Um * ((float)mq[e] > 0.0f ? 1.0f : 0.2f);
-                    gm[ot][4 * gq + e] = v;
-                    mx = fmaxf(mx, fabsf(v));
-                }
+                f32x4 v;
+                mpre_of(ot, gq, v);
+                mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
             }
+            __builtin_amdgcn_sched_barrier(0);
+        }
         mx = fmaxf(mx, __shfl_xor(mx, 32, WAVE));
         const float S_mp = A.scales[2 * (3 * L)];
         if (DRY) {
@@ -384,27 +394,30 @@ __global__ __launch_bounds__(256) void chain_pw16_kernel(Args A) {
 #pragma unroll
             for (int d = 16; d >= 1; d >>= 1) m4 = fmaxf(m4, __shfl_xor(m4, d, WAVE));
             if (lane == 0) atomicMax(A.gmax + 3 * L, __float_as_uint(m4));
-        } else {
-            if (A.sat && live && __any(mx * S_mp > 65504.0f) && lane == 0) atomicAdd(A.sat, 1u);
-            if (live) {
-                _Float16* d = A.g16 + (size_t)(3 * L) * slab16 + ((size_t)tile_T * 8 * 32 + j) * 32 + 4 * h;
-#pragma unroll
-                for (int ot = 0; ot < 8; ++ot)
-#pragma unroll
-                    for (int gq = 0; gq < 4; ++gq) {
-                        float q4[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) q4[e] = __builtin_amdgcn_fmed3f(gm[ot][4 * gq + e] * S_mp, -65504.0f, 65504.0f);
-                        *reinterpret_cast<u32x2_*>(d + ot * 1024 + 8 * gq) = u32x2_{pk_f16(q4[0], q4[1]), pk_f16(q4[2], q4[3])};
-                    }
-            }
+        } else if (A.sat && live && __any(mx * S_mp > 65504.0f) && lane == 0) {
+            atomicAdd(A.sat, 1u);
         }
         const float Tm = pow2_to_2p14(mx);                                               // the point's own maximum: exact, no bound needed
         u32x4 fm[16];
+        _Float16* gmp_dst = A.g16 + (size_t)(3 * L) * slab16 + ((size_t)tile_T * 8 * 32 + j) * 32 + 4 * h;
 #pragma unroll
-        for (int ot = 0; ot < 8; ++ot)
+        for (int ot = 0; ot < 8; ++ot) {
 #pragma unroll
-            for (int r = 0; r < 16; r += 2) fm[2 * ot + (r >> 3)][(r & 7) >> 1] = pk_f16(gm[ot][r] * Tm, gm[ot][r + 1] * Tm);
+            for (int gq = 0; gq < 4; ++gq) {
+                f32x4 v;
+                mpre_of(ot, gq, v);
+                if (!DRY && live) {
+                    float q4[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) q4[e] = __builtin_amdgcn_fmed3f(v[e] * S_mp, -65504.0f, 65504.0f);
+                    *reinterpret_cast<u32x2_*>(gmp_dst + ot * 1024 + 8 * gq) = u32x2_{pk_f16(q4[0], q4[1]), pk_f16(q4[2], q4[3])};
+                }
+                // elements r = 4 gq + e of tile ot: chunk 2 ot + (r >> 3), dword (r & 7) >> 1
+                fm[2 * ot + (gq >> 1)][2 * (gq & 1)] = pk_f16(v[0] * Tm, v[1] * Tm);
+                fm[2 * ot + (gq >> 1)][2 * (gq & 1) + 1] = pk_f16(v[2] * Tm, v[3] * Tm);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
         {
             const f16x8* unit = unit_begin(0) + lane;
             if (!DRY) {
@@ -515,7 +528,7 @@ static hipError_t launch_nt(const Args& A, hipStream_t stream) {
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) != hipSuccess) dev = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
-    const size_t lds_bytes = (size_t)2 * 32 * 1024 + (size_t)NT * 1024 + (size_t)4 * 32 * 33 * 4 + (size_t)2 * 4 * 32 * 8 * 4;
+    const size_t lds_bytes = (size_t)3 * 32 * 1024 + (size_t)NT * 1024 + (size_t)4 * 32 * 33 * 4 + (size_t)2 * 4 * 32 * 8 * 4;
     if (hipError_t e = hipFuncSetAttribute((const void*)chain_pw16_kernel<NT, DRY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)) return e;
     const FieldArgs& f = A.f;
     const long long want = (f.total_tiles / f.tiles_per_image) * ((f.tiles_per_image + 3) / 4);

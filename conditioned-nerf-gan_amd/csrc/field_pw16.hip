@@ -9,8 +9,8 @@
 // 1.5 M MACs per point at H = 256, two thirds of them in the mapping network's second Linear, whose 2 L H outputs are never
 // materialised: per 32-channel output tile the kernel runs three accumulations (fr and ph against m, pre against x) and combines them
 // in the epilogue.  Same construction as field_h3.hip: one wave per 32-point tile, accumulator registers converted pairwise are the
-// next B operands, four waves of a block walk one flat sequence of weight units through a two-slot LDS ring filled by LDS-DMA (one
-// barrier per unit, explicit vmcnt wait in front of it).  The sequence per tile, in the order the packed stream holds it:
+// next B operands, four waves of a block walk one flat sequence of weight units through a three-slot LDS ring filled by LDS-DMA (one
+// barrier per unit, counted vmcnt wait in front of it).  The sequence per tile, in the order the packed stream holds it:
 //     Wm1 (8 output tiles x 2 k-chunks) | W_0 (NT x 2) | layer 0: per output tile t  fr_t, ph_t  (16 k-chunks each: K = 256)
 //     | layers 1..L-1: per t  fr_t, pre_t (2 NT chunks: K = H), ph_t | head (1 tile x 2 NT chunks)
 // i.e. two unit sizes: 16 PARTS pieces of 1 KiB for everything multiplied by m (and Wm1), 2 NT PARTS for what is multiplied by x.
@@ -213,7 +213,9 @@ __global__ __launch_bounds__(256) void field_pw16_kernel(FieldArgs a) {
     constexpr int BIG = KCM * PARTS, SMALL = KCH * PARTS;           // 1-KiB pieces per weight unit
     constexpr int SLOT_FR = BIG * 64;                               // f16x8 fragments per LDS slot
     f16x8* lds = reinterpret_cast<f16x8*>(smem);
-    float* lds_c = reinterpret_cast<float*>(smem + 2 * (size_t)SLOT_FR * 16);
+    constexpr int SLOTS = 3;                                        // weight units in LDS: one being read, two being copied
+    constexpr int PWMIN = SMALL / 4;                                // copy instructions per wave and unit: at least this many
+    float* lds_c = reinterpret_cast<float*>(smem + SLOTS * (size_t)SLOT_FR * 16);
     const int L = a.L;
     const float* c_m1 = lds_c;
     const float* c_lay = lds_c + 256;
@@ -256,20 +258,26 @@ __global__ __launch_bounds__(256) void field_pw16_kernel(FieldArgs a) {
             dma_k = 0;
             dma_src = w_units;
         }
-        dma_slot ^= 1;
+        dma_slot = dma_slot == SLOTS - 1 ? 0 : dma_slot + 1;
     };
-    // every wave, at the start of every unit: its share of the unit's copy has landed (LDS-DMA is counted by vmcnt; the wait is
-    // written out: DESIGN.md 3.11), the barrier publishes the unit and retires the reads of the other slot, which is refilled next
-    auto unit_begin = [&]() -> const f16x8* {
-        wait_vmcnt<0>();
-        __syncthreads();
+    // Every wave, at the start of every unit: its share of the unit's copy has landed.  The copy of unit k is requested two units
+    // earlier (three slots); LDS-DMA is counted by vmcnt, which retires in order, and the wait is written out: at most N
+    // operations may stay in flight, N = a lower bound on what the wave has issued since that request -- the copy instructions of unit
+    // k + 1 (>= PWMIN) and, in the activation-storing forward, the `stores` of the epilogue in between (16 per output tile: 4 quads x
+    // {y, cos, cos f, cos 15 pre}; an idle wave stores nothing).  The barrier orders LDS only: the stores stay in flight across it.
+    bool store_live = false;
+    auto unit_begin = [&](int stores) -> const f16x8* {
+        if (STORE && store_live && stores >= 16) wait_vmcnt<16 + PWMIN>();
+        else wait_vmcnt<PWMIN>();
+        lds_only_barrier();
         dma_next();
         const f16x8* unit = lds + use_slot * SLOT_FR;
-        use_slot ^= 1;
+        use_slot = use_slot == SLOTS - 1 ? 0 : use_slot + 1;
         return unit;
     };
 
     for (int i = threadIdx.x; i < a.bias_floats; i += 256) lds_c[i] = a.bias[i];
+    dma_next();
     dma_next();
 
     for (long long g = g_begin; g < g_end; g += blk_per_cls) {
@@ -284,6 +292,7 @@ __global__ __launch_bounds__(256) void field_pw16_kernel(FieldArgs a) {
         const size_t slab16 = (size_t)a.total_tiles * NT * 1024;
         PwStore st;
         st.live = STORE && tile_in_image < a.tiles_per_image;
+        store_live = st.live;
         st.cslab = slab16;
         st.blk_h = STORE ? reinterpret_cast<_Float16*>(a.act_h) + ((size_t)tile_T * NT * 32 + j) * 32 + 4 * h : nullptr;
         st.blk_c = STORE ? reinterpret_cast<_Float16*>(a.act_c) + ((size_t)tile_T * NT * 256 + lane) * 4 : nullptr;
@@ -291,7 +300,7 @@ __global__ __launch_bounds__(256) void field_pw16_kernel(FieldArgs a) {
         // ---- mapping hidden layer: m = LeakyReLU_0.2(Wm1 feat + bm1), 8 output tiles ----------------------------------------
         Split2 m[KCM];
         {
-            const f16x8* unit = unit_begin();
+            const f16x8* unit = unit_begin(0);
             const f32x16 feat = input_tile_reduce(it, px, py, pz, h);
             float fv[16];
 #pragma unroll
@@ -338,7 +347,7 @@ __global__ __launch_bounds__(256) void field_pw16_kernel(FieldArgs a) {
         // ---- layer 0 reads the world position: pre_0 of all NT output tiles from one unit -----------------------------------------
         f32x16 acc0[NT];
         {
-            const f16x8* unit = unit_begin();
+            const f16x8* unit = unit_begin(0);
             float fv[8];
 #pragma unroll
             for (int r = 0; r < 8; ++r) fv[r] = 0.0f;
@@ -376,7 +385,8 @@ __global__ __launch_bounds__(256) void field_pw16_kernel(FieldArgs a) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 f32x16 fr = load_chan16(ci + H, t, h);
-                fr = tile_kc<KCM, 6>(unit_begin(), m, fr, lane, [&](int c) {
+                // (t = 0 of a later layer: the previous layer's last epilogue, 16 stores, sits in the interval before this one)
+                fr = tile_kc<KCM, 6>(unit_begin((t == 0 && !FIRST) ? 16 : 0), m, fr, lane, [&](int c) {
                     if (t > 0 && (c & 1)) {
                         if constexpr (STORE) film_pair_store(q_prev, pre_prev, ph_prev, c1, c2, t - 1, c - 1, &out[2 * (t - 1)], st);
                         else film_pair(q_prev, ph_prev, c1, c2, c - 1, &out[2 * (t - 1)]);
@@ -387,16 +397,16 @@ __global__ __launch_bounds__(256) void field_pw16_kernel(FieldArgs a) {
                     pre = acc0[t];
                 } else {
                     pre = load_chan16(ci, t, h);
-                    pre = tile_kc<KCH, 0>(unit_begin(), in, pre, lane, [](int) {});
+                    pre = tile_kc<KCH, 0>(unit_begin(t > 0 ? 16 : 0), in, pre, lane, [](int) {});        // (tile t-1's epilogue rode under fr_t)
                 }
                 f32x16 ph = load_chan16(ci + 2 * H, t, h);
                 if constexpr (STORE) {
-                    ph = tile_kc<KCM, 0>(unit_begin(), m, ph, lane, [](int) {});
+                    ph = tile_kc<KCM, 0>(unit_begin(t > 0 ? 16 : 0), m, ph, lane, [](int) {});
                     q_prev = fr;
                     pre_prev = pre;
                 } else {
                     f32x16 q;
-                    ph = tile_kc<KCM, 1>(unit_begin(), m, ph, lane, [&](int c) { q[c] = fr[c] * pre[c]; });
+                    ph = tile_kc<KCM, 1>(unit_begin(0), m, ph, lane, [&](int c) { q[c] = fr[c] * pre[c]; });
                     q_prev = q;
                 }
                 ph_prev = ph;
@@ -421,7 +431,7 @@ __global__ __launch_bounds__(256) void field_pw16_kernel(FieldArgs a) {
         }
         // ---- head -------------------------------------------------------------------------------------------------------------
         {
-            const f16x8* unit = unit_begin();
+            const f16x8* unit = unit_begin(16);                  // (the last layer's last epilogue sits in the interval before this one)
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
@@ -452,7 +462,7 @@ static hipError_t launch_inst(const FieldArgs& a, hipStream_t stream) {
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) != hipSuccess) dev = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
-    const size_t lds_bytes = 2 * (size_t)KCM * PARTS * 1024 + (size_t)a.bias_floats * 4;
+    const size_t lds_bytes = 3 * (size_t)KCM * PARTS * 1024 + (size_t)a.bias_floats * 4;
     if (lds_bytes > LDS_LIMIT) return hipErrorInvalidValue;
     if (hipError_t e = hipFuncSetAttribute((const void*)field_pw16_kernel<NT, STORE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT)) return e;
     const long long want = (a.total_tiles / a.tiles_per_image) * ((a.tiles_per_image + 3) / 4);
