@@ -43,8 +43,11 @@ def n_matrices(net):
     return ops.n_matrices(net)
 
 
-def macs_per_point(C, H, n_layers):
-    """n_layers = weight matrices before the head (a residual block counts two)."""
+def macs_per_point(C, H, n_layers, net=None):
+    """n_layers = weight matrices before the head (a residual block counts two).  Per-point FiLM networks (TALLSIREN): the mapping
+    MLP runs per point -- Wm1 (C x 256), 2 n_layers H rows of Wm2 (256 wide) -- and layer 0 reads the position (3 inputs)."""
+    if net is not None and net.spec.layers[0] == "pfilm":
+        return C * 256 + 2 * n_layers * H * 256 + 3 * H + (n_layers - 1) * H * H + H * 4      # TALLSIREN, H 256: 1,517,312 (SURVEY.md 8a)
     return C * H + (n_layers - 1) * H * H + H * 4             # SHORTSIREN_FG: 205,824 (SURVEY.md 8a)
 
 
@@ -256,10 +259,12 @@ def fast_path(args, gen, fvol, glob, cam, meta, evs, precision="fp16x3"):
     finally:
         gen.siren.precision = "fp32"
     ms = float(np.mean([evs.elapsed_ms(events[4 * i + k], events[4 * i + k + 1]) for i in range(steps) for k in (0, 2)]))
-    flops = 2.0 * macs_per_point(32, args.hidden, n_matrices(gen.siren)) * B * R * R * S
+    flops = 2.0 * macs_per_point(32, args.hidden, n_matrices(gen.siren), gen.siren) * B * R * R * S
+    pfilm = gen.siren.spec.layers[0] == "pfilm"
     return {"value": B * R * R / dt, "unit": "rays/s", "ms_per_step": dt * 1e3,
             "dtype": "fp16x3 (fp32-equivalent split, fp32 accumulate)" if mfmas == 3 else "fp16 products, fp32 accumulate (tolerance 2e-2, not the 1e-4 gate)",
-            "kernel": "field_h3_kernel<8>" if mfmas == 3 else "h1::field_h3_kernel<8> (single pass)", "avg_launch_ms": ms,
+            "kernel": ("h3::pw::field_pw16_kernel<8>" if mfmas == 3 else "h1::pw::field_pw16_kernel<8> (single pass)") if pfilm else
+                      ("field_h3_kernel<8>" if mfmas == 3 else "h1::field_h3_kernel<8> (single pass)"), "avg_launch_ms": ms,
             "algorithmic_tflops": flops / (ms * 1e-3) / 1e12,
             "fp16_mfma_tflops": mfmas * flops / (ms * 1e-3) / 1e12, "fp16_mfma_peak": PEAK_F16_MFMA_TFLOPS,
             "frac_of_fp16_mfma_peak": mfmas * flops / (ms * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS}
@@ -274,7 +279,7 @@ def train_step_timing(args, gen, fvol, glob, cam, evs):
     forward's algorithmic FLOPs (forward + two gradient GEMMs per layer)."""
     B, R, S = args.batch, args.img_size, args.num_steps
     meta = dict(clamp_mode="relu", nerf_noise=1.0, white_back=True, hierarchical_sample=True)
-    flops = 3 * 2 * 2.0 * macs_per_point(32, args.hidden, n_matrices(gen.siren)) * B * R * R * S
+    flops = 3 * 2 * 2.0 * macs_per_point(32, args.hidden, n_matrices(gen.siren), gen.siren) * B * R * R * S
     out = {"images": B, "forward_ms_fp32": None}
     keep = (gen.siren.precision, getattr(gen.siren, "backward_precision", "fp32"))
     gen.train()
@@ -285,7 +290,7 @@ def train_step_timing(args, gen, fvol, glob, cam, evs):
             gl = glob.detach().clone().requires_grad_(True)
             torch.cuda.reset_peak_memory_stats()
             times, fwd = [], []
-            for i in range(3):
+            for i in range(5):       # (the first two settle the caching allocator: it takes its second multi-GiB block in iteration 1)
                 for p in gen.parameters():
                     p.grad = None
                 fv.grad = gl.grad = None
@@ -296,7 +301,7 @@ def train_step_timing(args, gen, fvol, glob, cam, evs):
                 t1 = time.perf_counter()
                 (px.square().mean() + dp.mean()).backward()
                 torch.cuda.synchronize()
-                if i > 0:
+                if i > 1:
                     times.append(time.perf_counter() - t0)
                     fwd.append(t1 - t0)
             dt = float(np.median(times))
@@ -718,16 +723,19 @@ def main():
         kern_ms += [evs.elapsed_ms(e[0], e[1]), evs.elapsed_ms(e[2], e[3])]
     avg_ms = float(np.mean(kern_ms))
     n_layers = n_matrices(gen.siren)
-    flops_per_launch = 2.0 * macs_per_point(32, args.hidden, n_layers) * B * R * R * S
+    flops_per_launch = 2.0 * macs_per_point(32, args.hidden, n_layers, gen.siren) * B * R * R * S
+    pfilm = gen.siren.spec.layers[0] == "pfilm"
     achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
     split = args.precision == "fp16x3"
     if split:      # priced per issued flop: three fp16 MFMAs per fp32 product, against the dense fp16 MFMA peak
-        roof = {"kernel": "field_h3_kernel<8> (sample + trilinear lookup + FiLM-SIREN MLP, fp16x3 split, fp32 accumulate)",
+        roof = {"kernel": ("pw::field_pw16_kernel<8> (sample + trilinear lookup + mapping MLP + per-point FiLM-SIREN, fp16x3 split, fp32 accumulate)" if pfilm else
+                           "field_h3_kernel<8> (sample + trilinear lookup + FiLM-SIREN MLP, fp16x3 split, fp32 accumulate)"),
                 "bound": "mfma", "achieved": 3 * achieved, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": 3 * achieved / PEAK_F16_MFMA_TFLOPS, "traffic": None, "algorithmic_tflops": achieved}
         pk = pmc_bytes("void cnerf::h3::field_h3_kernel")
     else:
-        roof = {"kernel": "field_tile_kernel<8> (sample + trilinear lookup + FiLM-SIREN MLP, fp32 MFMA)",
+        roof = {"kernel": ("field_pw_kernel<8> (sample + trilinear lookup + mapping MLP + per-point FiLM-SIREN, fp32 MFMA)" if pfilm else
+                           "field_tile_kernel<8> (sample + trilinear lookup + FiLM-SIREN MLP, fp32 MFMA)"),
                 "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None}
         pk = pmc_bytes("void cnerf::field_tile_kernel")

@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""Per-point FiLM training step, exact and half-precision backward in one process (allocator behaviour between the two)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, cnerf_amd
+from cnerf_amd.generators import ImplicitGenerator3d
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+order = sys.argv[2].split(",") if len(sys.argv) > 2 else ["fp32", "fp16"]
+dev = torch.device("cuda:0"); torch.manual_seed(0)
+gen = ImplicitGenerator3d("TALLSIREN", 32, 3, 4, 256).to(dev); gen.set_device(dev); gen.train()
+fvol = torch.randn(B, 32, 64, 64, 64, device=dev, requires_grad=True)
+cam = torch.eye(4, device=dev).unsqueeze(0).repeat(B, 1, 1); cam[:, 2, 3] = -1.0
+for bp in order:
+    gen.siren.precision, gen.siren.backward_precision = ("fp32", "fp32") if bp == "fp32" else ("fp16x3", "fp16")
+    for i in range(4):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        px, dp = gen(fvol, cam, 128, 49.134342641202636, 0.25, 1.95, 64, True, clamp_mode="relu", nerf_noise=1.0, white_back=True)
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        (px.square().mean() + dp.mean()).backward()
+        torch.cuda.synchronize(); t2 = time.perf_counter()
+        print(f"{bp} iter {i}: fwd {1e3*(t1-t0):.1f} bwd {1e3*(t2-t1):.1f} ms | reserved {torch.cuda.memory_reserved()/2**30:.1f} GiB allocated {torch.cuda.memory_allocated()/2**30:.1f} GiB", flush=True)
+    del px, dp
+    torch.cuda.empty_cache()
