@@ -59,7 +59,8 @@ extern "C" {
 #define CNERF_LAYER_RES 2  /* y = sin(x + W2 sin(W1 x + b1) + b2) */
 #define CNERF_LAYER_PFILM 3 /* y = sin(freq(p) * (W x + b) + phase(p)): per-point FiLM from the mapping MLP of the looked-up
                                feature (siren.py:163-177, 81-101); all layers of the network must be of this kind, layer 0
-                               then reads the world position (K = 3) and the features feed the mapping MLP only */
+                               then reads the world position (K = 3) and the features feed the mapping MLP only.  All three
+                               precisions (ABI v7: CNERF_PREC_FP16X3 / CNERF_PREC_FP16 in csrc/field_pw16.hip) */
 
 typedef struct cnerf_cfg {
     int32_t B;            /* images in this call */
@@ -169,7 +170,7 @@ typedef struct cnerf_aux {
      * immediately before / after the field kernel of the coarse pass ([0],[1]) and of the fine pass ([2],[3]).
      * NULL entries are skipped.  bench.py uses them to time the dominant kernel inside the timed region. */
     void* field_events[4];
-    /* Optional (ABI v4), precision CNERF_PREC_FP16X3 only: keep the activations of the two field passes for the half-precision
+    /* Optional (ABI v4), precision CNERF_PREC_FP16X3 only, not for CNERF_LAYER_PFILM networks: keep the activations of the two field passes for the half-precision
      * backward instead of re-computing them there -- act16[0] coarse pass, act16[1] fine pass; each {feat (T, n_in, 32, 32),
      * h (n_mats, T, H/32, 32, 32), c (same)} fp16 in the TB16 layout over ALL images of the call (T = B * ceil(R*R*S / 32)).
      * 4 KiB per sample point at H = 256, 4 layers: sized for the 288 GB of HBM of an MI355X (batch 8 at 128x128x(64+64): 69 GB).

@@ -19,7 +19,7 @@ def dptr(t):
 
 
 @pytest.mark.parametrize("name,fwd,bwd", [("short_fg_small", "fp32", "fp32"), ("short_fg_small", "fp16x3", "fp16"), ("short_fres_small", "fp32", "fp32"),
-                                          ("tall_dres_small", "fp16x3", "fp16"), ("short_fg_nohier", "fp32", "fp32")])
+                                          ("tall_dres_small", "fp16x3", "fp16"), ("short_fg_nohier", "fp32", "fp32"), ("tallsiren_small", "fp16x3", "fp16")])
 def test_forward_and_backward_through_ctypes_only(golden, name, fwd, bwd):
     import cnerf_amd
     L = cnerf_amd._lib                      # struct definitions and prototypes of include/cnerf.h; nothing else of the package is used
@@ -31,8 +31,10 @@ def test_forward_and_backward_through_ctypes_only(golden, name, fwd, bwd):
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     ok = lambda rc, what: (_ for _ in ()).throw(AssertionError(f"{what}: rc {rc}: {lib.cnerf_last_error().decode()}")) if rc else None
 
-    spec_layers = {"SHORTSIREN_FG": ["film"] * 4, "SHORTSIREN_FRes": ["sine", "res", "sine"], "TALLSIREN_dRes": ["sine", "res", "res", "sine"]}[m["variant"]]
-    sigmoid = m["variant"] != "TALLSIREN_dRes"
+    spec_layers = {"SHORTSIREN_FG": ["film"] * 4, "SHORTSIREN_FRes": ["sine", "res", "sine"], "TALLSIREN_dRes": ["sine", "res", "res", "sine"],
+                   "TALLSIREN": ["pfilm"] * 8}[m["variant"]]
+    sigmoid = m["variant"] not in ("TALLSIREN_dRes", "TALLSIREN")
+    pfilm = spec_layers[0] == "pfilm"
     B, R, S, H, V, Cc = m["B"], m["R"], m["S"], m["H"], g["feature_volume"].shape[-1], m["C"]
     hier = bool(m["hierarchical"])
     P, npi = R * R, R * R * S
@@ -71,6 +73,9 @@ def test_forward_and_backward_through_ctypes_only(golden, name, fwd, bwd):
         else:
             bind("w", "b", "w", "b", i, f"network.{i}.layer")
     bind("w_final", "b_final", "w_final", "b_final", None, "final_layer")
+    if pfilm:            # the mapping MLP is evaluated per point inside the kernels (ABI v7: its gradients come back through cnerf_field_param_grads)
+        bind("map_w1", "map_b1", "map_w1", "map_b1", None, "mapping_network.network.0")
+        bind("map_w2", "map_b2", "map_w2", "map_b2", None, "mapping_network.network.2")
 
     # FiLM mapping Linear on the host (K6): freq = 15 * f + 30
     n_film = spec_layers.count("film")
