@@ -56,7 +56,7 @@ AUX_FIELDS = ("coarse_points", "coarse_z", "coarse_rgb_sigma", "coarse_weights",
 
 
 class Act16(C.Structure):
-    _fields_ = [("feat", C.c_void_p), ("h", C.c_void_p), ("c", C.c_void_p)]
+    _fields_ = [("feat", C.c_void_p), ("h", C.c_void_p), ("c", C.c_void_p), ("amax", C.c_void_p)]
 
 
 class Aux(C.Structure):

@@ -590,15 +590,19 @@ int cnerf_render_forward(const cnerf_cfg* cfg, const cnerf_volumes* vols, const 
     if (keep) {
         if (cfg->precision != CNERF_PREC_FP16X3 && cfg->precision != CNERF_PREC_FP16)
             return fail(CNERF_EINVAL, "render_forward: act16 needs precision CNERF_PREC_FP16X3 or CNERF_PREC_FP16");
-        if (cfg->layer_kind[0] == CNERF_LAYER_PFILM) return fail(CNERF_EINVAL, "render_forward: act16 is not available for the per-point FiLM family");
         if (!aux->act16[0].feat || !aux->act16[0].c || (hier && (!aux->act16[1].feat || !aux->act16[1].h || !aux->act16[1].c)))
             return fail(CNERF_EINVAL, "render_forward: act16 is incomplete");
+        if (cfg->layer_kind[0] == CNERF_LAYER_PFILM) {
+            if (cfg->precision != CNERF_PREC_FP16X3) return fail(CNERF_EINVAL, "render_forward: per-point FiLM keeps its activations in precision CNERF_PREC_FP16X3 only");
+            if (!aux->act16[0].amax || (hier && !aux->act16[1].amax)) return fail(CNERF_EINVAL, "render_forward: act16.amax is NULL (per-point FiLM)");
+        }
     }
     auto keep_pass = [&](int i) {
         fa.act_points = (long long)cfg->B * npi;
         fa.act_feat = keep ? (float*)aux->act16[i].feat : nullptr;
         fa.act_h = keep ? (float*)aux->act16[i].h : nullptr;
         fa.act_c = keep ? (float*)aux->act16[i].c : nullptr;
+        fa.act_amax = keep ? (float*)aux->act16[i].amax : nullptr;
         fa.act_tb16 = keep ? 1 : 0;
     };
     keep_pass(0);
@@ -976,7 +980,7 @@ int backward_layout(const cnerf_cfg* c, int bprec, int cnt, bool have_act16, Bac
                                   "GEMMs on the host (cnerf_field_backward + cnerf_weight_grad + cnerf_scatter_features); backward_precision fp16 runs here");
     if (cnt < 1 || cnt > c->B) return fail(CNERF_EINVAL, "render_backward: images_per_chunk=%d out of [1,B]", cnt);
     if (c->layer_kind[0] == CNERF_LAYER_PFILM) {      // chain_pw16.hip: three stored derivatives and three gradient slabs per layer, m and g_mpre
-        if (have_act16) return fail(CNERF_EINVAL, "render_backward: kept activations are not available for the per-point FiLM family");
+        if (have_act16 && cnt != c->B) return fail(CNERF_EINVAL, "render_backward: kept activations need images_per_chunk = B");
         if (c->precision != CNERF_PREC_FP16X3) return fail(CNERF_EINVAL, "render_backward: the fp16 backward re-runs the fp16x3 forward (cfg->precision)");
         const size_t H = c->H, NT = H / 32, Lc = c->L, npi = (size_t)c->R * c->R * c->S, tpi = (npi + 31) / 32;
         const size_t N = (size_t)c->B * npi, T = (size_t)cnt * tpi;
@@ -988,10 +992,10 @@ int backward_layout(const cnerf_cfg* c, int bprec, int cnt, bool have_act16, Bac
         auto take = [&](size_t bytes) { const size_t o = off; off += align256(bytes); return o; };
         L.gc = take(N * 4 * sizeof(float));
         L.gf = take(hier ? N * 4 * sizeof(float) : 0);
-        L.a_feat = take(T * 2 * 2048);
-        L.a_h = take((Lc * NT + 8) * T * 2048);
-        L.a_c = take(3 * Lc * NT * T * 2048);
-        L.a_amax = take(Lc * T * 32 * sizeof(float));
+        L.a_feat = take(have_act16 ? 0 : T * 2 * 2048);
+        L.a_h = take(have_act16 ? 0 : (Lc * NT + 8) * T * 2048);
+        L.a_c = take(have_act16 ? 0 : 3 * Lc * NT * T * 2048);
+        L.a_amax = take(have_act16 ? 0 : Lc * T * 32 * sizeof(float));
         L.a_g = take((3 * Lc * NT + 8) * T * 2048);
         L.a_go = take(T * 2048);
         L.gmax = take((3 * Lc + 2) * sizeof(uint32_t));
@@ -1100,12 +1104,8 @@ int cnerf_render_backward(const cnerf_cfg* cfg, int32_t bprec, int32_t cnt_max, 
         float* csh = (float*)(ws + L.csh);
         uint32_t* gmax = (uint32_t*)(ws + L.gmax);
         float* scales = (float*)(ws + L.scales);
-        char* a_feat = ws + L.a_feat;
-        char* a_h = ws + L.a_h;
-        char* a_c = ws + L.a_c;
         char* a_g = ws + L.a_g;
         char* a_go = ws + L.a_go;
-        float* a_amax = (float*)(ws + L.a_amax);
         if (hipError_t e = hipMemsetAsync(a_go, 0, (size_t)cnt_max * tpi * 2048, stream)) return hip_fail(e, "memset");
         for (int pass = 0; pass < (hier ? 2 : 1); ++pass) {
             const float* g_out = pass ? gf : gc;
@@ -1113,6 +1113,12 @@ int cnerf_render_backward(const cnerf_cfg* cfg, int32_t bprec, int32_t cnt_max, 
             for (int b0 = 0; b0 < B; b0 += cnt_max) {
                 const int cnt = b0 + cnt_max <= B ? cnt_max : B - b0;
                 const long long T = (long long)cnt * tpi;
+                // the pass's activations: kept by the forward (all images), or re-computed into the workspace
+                char* a_feat = have_act16 ? (char*)kept->act16[pass].feat : ws + L.a_feat;
+                char* a_h = have_act16 ? (char*)kept->act16[pass].h : ws + L.a_h;
+                char* a_c = have_act16 ? (char*)kept->act16[pass].c : ws + L.a_c;
+                float* a_amax = have_act16 ? (float*)kept->act16[pass].amax : (float*)(ws + L.a_amax);
+                if (have_act16 && (!a_feat || !a_h || !a_c || !a_amax)) return fail(CNERF_EINVAL, "render_backward: act16 of pass %d is incomplete", pass);
                 FieldArgs fa;
                 if (int rc = fill_field_args(fa, cfg, vols, grad_vols, packed, nullptr, nullptr, b0)) return rc;
                 if (!fa.lvl_grad[0]) return fail(CNERF_EINVAL, "render_backward: gradient volume is NULL");
@@ -1125,7 +1131,7 @@ int cnerf_render_backward(const cnerf_cfg* cfg, int32_t bprec, int32_t cnt_max, 
                     fa.mode = FIELD_MODE_FINE;
                     fa.fine_z = saved->fine_z + (size_t)b0 * npi;
                 }
-                {
+                if (!have_act16) {
                     FieldArgs fs = fa;
                     fs.rgb_sigma = (float*)a_g;      // (n,4) floats of head output nobody reads; the chain overwrites a_g entirely
                     fs.z_out = nullptr;

@@ -302,7 +302,9 @@ def render_forward(net, fvol, freq, phase, cam2world, img_size, fov, ray_start, 
     if act16 is not None:          # keep the field passes' activations (fp16 tile blocks) for the half-precision backward
         aux_s = aux_s if aux_s is not None else L.Aux()
         for i, bufs in enumerate(act16):
-            aux_s.act16[i].feat, aux_s.act16[i].h, aux_s.act16[i].c = (t.data_ptr() for t in bufs)
+            aux_s.act16[i].feat, aux_s.act16[i].h, aux_s.act16[i].c = (t.data_ptr() for t in bufs[:3])
+            if len(bufs) > 3:
+                aux_s.act16[i].amax = bufs[3].data_ptr()
     L.check(L.lib().cnerf_render_forward(C.byref(cfg), C.byref(vs), L.ptr(packed), L.ptr(_f32(freq)), L.ptr(_f32(phase)),
                                          L.ptr(cam2world), C.byref(r), L.ptr(pixels), L.ptr(depth),
                                          C.byref(aux_s) if aux_s is not None else None, L.ptr(ws), _stream()),
@@ -459,10 +461,16 @@ def resident_act16(net, levels, B, R, S, hier, dev):
     nslab = n_matrices(net)
     T = B * ((R * R * S + 31) // 32)
     n_pass = 2 if hier else 1
+    f16 = dict(dtype=torch.float16, device=dev)
+    if net.spec.layers[0] == "pfilm":      # field_pw16.hip: feature + position | y_l slabs then m | cos, cos f, cos 15 pre per layer | per-point maxima
+        blocks = 2 + nslab * NT + 8 + 3 * nslab * NT
+        if n_pass * T * 2048 * blocks + T * 2048 * (3 * nslab * NT + 9) > min(RESIDENT_BUDGET_BYTES, RESIDENT_FRACTION * free_device_bytes(dev)):
+            return None
+        return [(torch.empty((T, 2, 32, 32), **f16), torch.empty(((nslab * NT + 8) * T, 32, 32), **f16), torch.empty((3 * nslab, T, NT, 32, 32), **f16),
+                 torch.empty((nslab, T * 32), dtype=torch.float32, device=dev)) for _ in range(n_pass)]
     per_pass = T * 2048 * (n_in + 2 * nslab * NT)
     if n_pass * per_pass + T * 2048 * (nslab * NT + 1) > min(RESIDENT_BUDGET_BYTES, RESIDENT_FRACTION * free_device_bytes(dev)):
         return None
-    f16 = dict(dtype=torch.float16, device=dev)
     return [(torch.empty((T, n_in, 32, 32), **f16), torch.empty((nslab, T, NT, 32, 32), **f16), torch.empty((nslab, T, NT, 32, 32), **f16))
             for _ in range(n_pass)]
 
@@ -566,7 +574,9 @@ def render_backward(net, o, levels, freq, phase, cam2world, rng, saved, grad_pix
     if act16 is not None:
         aux = L.Aux()
         for i, bufs in enumerate(act16):
-            aux.act16[i].feat, aux.act16[i].h, aux.act16[i].c = (t.data_ptr() for t in bufs)
+            aux.act16[i].feat, aux.act16[i].h, aux.act16[i].c = (t.data_ptr() for t in bufs[:3])
+            if len(bufs) > 3:
+                aux.act16[i].amax = bufs[3].data_ptr()
     L.check(L.lib().cnerf_render_backward(C.byref(cfg), code, nb, C.byref(vs), C.byref(fp), L.ptr(packed), L.ptr(packed_bwd), L.ptr(freq), L.ptr(phase),
                                           L.ptr(cam2world), C.byref(r), C.byref(sv), C.byref(aux) if aux is not None else None,
                                           L.ptr(grad_pixels), L.ptr(grad_depth), C.byref(gp), L.ptr(g_freq), L.ptr(g_phase), C.byref(gvs),
@@ -592,7 +602,7 @@ class RenderFunction(torch.autograd.Function):
         need_grad = any(ctx.needs_input_grad)   # (grad mode is always off inside Function.forward)
         keys = SAVED_KEYS + (("coarse_points", "fine_points") if net.spec.layers[0] == "pfilm" else ())   # see _pfilm_backward
         act16 = None
-        if need_grad and backward_precision_of(net) == "fp16" and precision_of(net) in ("fp16x3", "fp16") and net.spec.layers[0] != "pfilm":
+        if need_grad and backward_precision_of(net) == "fp16" and precision_of(net) in (("fp16x3",) if net.spec.layers[0] == "pfilm" else ("fp16x3", "fp16")):
             act16 = resident_act16(net, levels, cam2world.shape[0], o["R"], o["S"], o["hier"], cam2world.device)
         pixels, depth, aux = render_forward(net, levels, fr, ph, cam2world, o["R"], o["fov"], o["ray_start"], o["ray_end"],
                                             o["S"], o["hier"], o["clamp_mode"], o["noise_std"], o["white_back"],

@@ -170,7 +170,7 @@ typedef struct cnerf_aux {
      * immediately before / after the field kernel of the coarse pass ([0],[1]) and of the fine pass ([2],[3]).
      * NULL entries are skipped.  bench.py uses them to time the dominant kernel inside the timed region. */
     void* field_events[4];
-    /* Optional (ABI v4), precision CNERF_PREC_FP16X3 only, not for CNERF_LAYER_PFILM networks: keep the activations of the two field passes for the half-precision
+    /* Optional (ABI v4), precision CNERF_PREC_FP16X3 only: keep the activations of the two field passes for the half-precision
      * backward instead of re-computing them there -- act16[0] coarse pass, act16[1] fine pass; each {feat (T, n_in, 32, 32),
      * h (n_mats, T, H/32, 32, 32), c (same)} fp16 in the TB16 layout over ALL images of the call (T = B * ceil(R*R*S / 32)).
      * 4 KiB per sample point at H = 256, 4 layers: sized for the 288 GB of HBM of an MI355X (batch 8 at 128x128x(64+64): 69 GB).
@@ -179,6 +179,8 @@ typedef struct cnerf_aux {
         void* feat;
         void* h;
         void* c;
+        void* amax; /* ABI v7, CNERF_LAYER_PFILM networks only: (L, T * 32) floats; their feat is (T, 2, 32, 32), h L slabs (T, H/32, 32, 32)
+                       then m (T, 8, 32, 32), c 3 L slabs -- 16.5 KiB per sample point and pass at H = 256, L = 8 */
     } act16[2];
 } cnerf_aux;
 
