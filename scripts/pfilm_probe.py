@@ -19,5 +19,7 @@ for bp in order:
         (px.square().mean() + dp.mean()).backward()
         torch.cuda.synchronize(); t2 = time.perf_counter()
         print(f"{bp} iter {i}: fwd {1e3*(t1-t0):.1f} bwd {1e3*(t2-t1):.1f} ms | reserved {torch.cuda.memory_reserved()/2**30:.1f} GiB allocated {torch.cuda.memory_allocated()/2**30:.1f} GiB", flush=True)
+    with torch.no_grad():                  # the plain kernel too (profiles)
+        gen(fvol.detach(), cam, 128, 49.134342641202636, 0.25, 1.95, 64, True, clamp_mode="relu", nerf_noise=1.0, white_back=True)
     del px, dp
     torch.cuda.empty_cache()
