@@ -1441,6 +1441,55 @@ def test_forward_is_deterministic_over_many_launches(dev, precision):
                 assert torch.equal(px, ref[0]) and torch.equal(dp, ref[1]), (net, it, int((px != ref[0]).sum()))
 
 
+@pytest.mark.parametrize("precision", ["fp16x3", "fp16"])
+def test_per_point_film_is_deterministic_over_many_launches(dev, precision):
+    """The same regression for the per-point FiLM family's fp16 kernels, whose weight units run through a three-slot ring behind COUNTED
+    vmcnt waits (csrc/field_pw16.hip, chain_pw16.hip): twenty forwards of a TALLSIREN (fresh weight buffers every five) agree bit for
+    bit, and so do the forwards of four training steps (the activation-storing instantiation, stores in flight across the barriers);
+    the gradients of those steps agree to the order of fp32 atomics (volume scatter, weight reductions: not bit-reproducible by design)."""
+    import cnerf_amd
+    from cnerf_amd.generators import ImplicitGenerator3d
+    R, S, V, B = 64, 33, 16, 2                         # 33 samples: ragged last tiles, idle waves in the last tile group
+    torch.manual_seed(1)
+    fvol = torch.randn(B, 32, V, V, V, device=dev)
+    cam = torch.eye(4, device=dev).unsqueeze(0).repeat(B, 1, 1).contiguous()
+    cam[:, 2, 3] = -1.0
+    rng = {"u_strat": torch.rand(B, R * R, S, device=dev), "u_fine": torch.rand(B, R * R, S, device=dev)}
+    ref = None
+    for net in range(4):
+        torch.manual_seed(2)
+        gen = ImplicitGenerator3d("TALLSIREN", 32, 3, 4, 256).to(dev)
+        gen.set_device(dev)
+        gen.siren.precision = precision
+        with torch.no_grad():
+            gen.siren.final_layer.weight[3] *= 40
+        for it in range(5):
+            with torch.no_grad():
+                px, dp = gen(fvol, cam, R, 49.13, 0.25, 1.95, S, True, clamp_mode="relu", nerf_noise=0.0, white_back=True, _rng=rng)
+            if ref is None:
+                ref = (px.clone(), dp.clone())
+            else:
+                assert torch.equal(px, ref[0]) and torch.equal(dp, ref[1]), (net, it, int((px != ref[0]).sum()))
+    if precision != "fp16x3":
+        return
+    gen.siren.backward_precision = "fp16"
+    gen.train()
+    gref = None
+    for it in range(4):
+        fv = fvol.clone().requires_grad_(True)
+        for p_ in gen.parameters():
+            p_.grad = None
+        px, dp = gen(fv, cam, R, 49.13, 0.25, 1.95, S, True, clamp_mode="relu", nerf_noise=0.0, white_back=True, _rng=rng)
+        assert torch.equal(px, ref[0]) and torch.equal(dp, ref[1]), ("storing forward", it, int((px != ref[0]).sum()))
+        (px.square().mean() + dp.mean()).backward()
+        grads = [fv.grad] + [p_.grad for p_ in gen.parameters()]
+        if gref is None:
+            gref = [g_.clone() for g_ in grads]
+        else:
+            for a_, b_ in zip(grads, gref):
+                assert (a_ - b_).norm() <= 1e-5 * b_.norm() + 1e-30, (it, float((a_ - b_).norm() / b_.norm()))
+
+
 @pytest.mark.parametrize("precision", ["fp32", "fp16x3"])
 def test_config4_per_gpu_batch_is_batch_invariant(dev, precision):
     """BASELINE config 4's per-GPU workload -- 8 images of 128x128 rays x (64 + 64) samples, 64^3 volumes, hidden 256, what bench.py
