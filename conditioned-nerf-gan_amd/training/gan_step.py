@@ -74,7 +74,14 @@ class CommMeter:
 
 def default_metadata(img_size=128, num_steps=64, batch_size=8, batch_split=4, siren_type="SHORTSIREN_FG", hidden_dim=256):
     """The render / optimisation hyper-parameters of configs/thousand/{default,special}.py for the direct-feature-volume
-    setting (unet3d encoder -> (feature volume, global feature) -> FG field networks)."""
+    setting (unet3d encoder -> (feature volume, global feature) -> FG field networks).  Field networks without a global feature
+    (TALLSIREN -- per-point FiLM from the looked-up feature, input = world position --, the plain-sine / residual families) take the bare
+    feature volume: the encoder then returns it alone and z_dim is its channel count (siren.py:232-331, 333-488)."""
+    from ..generators import siren as _siren
+    spec = getattr(_siren, siren_type).spec
+    gen = {"siren_type": siren_type, "z_dim": 256, "input_dim": 32, "output_dim": 4, "hidden_dim": hidden_dim}
+    if not spec.has_global:
+        gen.update(z_dim=32, input_dim=3 if spec.input == "xyz" else 32)
     return {
         "img_size": img_size, "num_steps": num_steps, "batch_size": batch_size, "batch_split": batch_split,
         "fov": 49.134342641202636, "ray_start": 0.25, "ray_end": 1.95, "cam_r_start": 0.7, "cam_r_end": 1.5,
@@ -82,8 +89,8 @@ def default_metadata(img_size=128, num_steps=64, batch_size=8, batch_split=4, si
         "fade_steps": 2000, "r1_lambda": 10, "grad_clip": 1, "betas": (0.0, 0.9), "weight_decay": 0,
         "gen_lr": 5e-5, "disc_lr": 2e-4, "enc_lr": 5e-5, "photo_loss": True, "enable_discriminator": True,
         "random_gen_img": True,
-        "generator": {"siren_type": siren_type, "z_dim": 256, "input_dim": 32, "output_dim": 4, "hidden_dim": hidden_dim},
-        "unet": {"in_channels": 4, "out_channels": 32, "f_maps": 32, "num_levels": 4, "return_global": True},
+        "generator": gen,
+        "unet": {"in_channels": 4, "out_channels": 32, "f_maps": 32, "num_levels": 4, "return_global": bool(spec.has_global)},
     }
 
 
