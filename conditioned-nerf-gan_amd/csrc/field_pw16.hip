@@ -15,9 +15,10 @@
 //     | layers 1..L-1: per t  fr_t, pre_t (2 NT chunks: K = H), ph_t | head (1 tile x 2 NT chunks)
 // i.e. two unit sizes: 16 PARTS pieces of 1 KiB for everything multiplied by m (and Wm1), 2 NT PARTS for what is multiplied by x.
 //
-// Epilogue.  Every accumulator starts from its bias in accumulator units (S b; S (bm2 + 2) for fr: 15 fr + 30 = 15 (fr + 2)), so
-//     u = arg / 2 pi = accf accp c1 + accph c2,    c1 = 15 / (2 pi S_f S_pre),  c2 = 1 / (2 pi S_ph)      (per layer, prepared on the device)
-// is two multiplies and one fma per element, then the exact reduction u - rint(u) and v_sin_f32 (which takes revolutions).  Rounding:
+// Epilogue.  Every accumulator starts from its bias in accumulator units (S b), and 15 fr + 30 = 15 (fr + 2), so
+//     u = arg / 2 pi = (accf + 2 S_f) accp c1 + accph c2,    c1 = 15 / (2 pi S_f S_pre),  c2 = 1 / (2 pi S_ph)      (per layer, prepared on the device)
+// is an add, two multiplies and one fma per element (the 2 S_f is added to the FINISHED accumulator: started from S_f (bm2 + 2) the 48 partial
+// sums of a product each round at the magnitude of 2 S_f -- rgb of `tallsiren_small` 9.6e-5 from the reference instead of 3e-5), then the exact reduction u - rint(u) and v_sin_f32 (which takes revolutions).  Rounding:
 // the product accf accp and the fma round at the magnitude of the argument like the reference's own freq * x + phase does.
 // The epilogue of output tile t-1 runs under the 48 MFMAs of fr_t (always 16 k-chunks: one element pair per two chunks), accf accp
 // under those of ph_t: 9 MFMAs per accumulator register against 3 in field_h3.hip -- the vector work is covered.
@@ -145,7 +146,7 @@ struct PwStore {
     _Float16* blk_h;       // y_l: the lane's row in channel tile 0 of the slab (+ 4 h)
     _Float16* blk_c;       // cos: fragment (tile, t = 0, quad 0, lane) of slab 3 l
     size_t cslab;          // fp16 elements per COS16 slab
-    float kf, kp;          // accf -> f, accp -> 15 pre
+    float kf, kp, k2;      // accf + k2 -> f (x kf), accp -> 15 pre (x kp)
     float amax;
     float s[2], c[2], cf[2], cp[2];     // the first pair of a quad, held until the second arrives
     bool live;
@@ -156,12 +157,13 @@ __device__ __forceinline__ void film_pair_store(const f32x16& fr, const f32x16& 
     float sn[2], cs[2], cf[2], cp[2];
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
-        const float q = fr[r + e] * pre[r + e];
+        const float fa = fr[r + e] + st.k2;
+        const float q = fa * pre[r + e];
         const float u = __builtin_fmaf(q, c1, ph[r + e] * c2);
         const float a = u - __builtin_rintf(u);
         sn[e] = __builtin_amdgcn_sinf(a);
         cs[e] = __builtin_amdgcn_cosf(a);
-        cf[e] = __builtin_amdgcn_fmed3f(cs[e] * (fr[r + e] * st.kf), -65504.0f, 65504.0f);
+        cf[e] = __builtin_amdgcn_fmed3f(cs[e] * (fa * st.kf), -65504.0f, 65504.0f);
         cp[e] = __builtin_amdgcn_fmed3f(cs[e] * (pre[r + e] * st.kp), -65504.0f, 65504.0f);
         st.amax = fmaxf(st.amax, fmaxf(fabsf(cf[e]), fabsf(cp[e])));
     }
@@ -201,7 +203,7 @@ __device__ __forceinline__ TilePoint tile_of_group(const FieldArgs& a, long long
 struct FirstLayer { static constexpr bool value = true; };
 struct LaterLayer { static constexpr bool value = false; };
 
-// Constants in LDS (a.bias, written by pw16_consts_kernel):  bm1 S (256) | per layer: b_l S_pre, (bm2 + 2) S_f, bm2 S_ph (3 H) | head bias (4)
+// Constants in LDS (a.bias, written by pw16_consts_kernel):  bm1 S (256) | per layer: b_l S_pre, bm2 S_f, bm2 S_ph (3 H) | head bias (4)
 // | 1 / S of Wm1, 1 / S of the head, per layer c1, c2, 15 / S_f, 15 / S_pre | the raw 1 / S and max|W| slots of the packing (unused here)
 // STORE: act_feat = TB16 (tiles, 2, 32, 32): the looked-up feature, the position; act_h = L slabs y_l (tiles, NT, 32, 32) then m (tiles, 8,
 // 32, 32); act_c = 3 L COS16 slabs; act_amax = (L, tiles * 32) floats.
@@ -376,8 +378,10 @@ __global__ __launch_bounds__(256) void field_pw16_kernel(FieldArgs a) {
             constexpr bool FIRST = decltype(first_tag)::value;
             const float* ci = c_lay + (size_t)l * 3 * H;              // starting values: pre, fr, ph
             const float c1 = c_scal[2 + 4 * l], c2 = c_scal[3 + 4 * l];
+            const float k2 = 30.0f / c_scal[4 + 4 * l];          // 2 S_f (a power of two): 15 fr + 30 = 15 (fr + 2), added to the finished accumulator
             if (STORE) {
                 st.kf = c_scal[4 + 4 * l];
+                st.k2 = k2;
                 st.kp = c_scal[5 + 4 * l];
                 st.amax = 1.0f;                        // |cos| <= 1
             }
@@ -406,7 +410,7 @@ __global__ __launch_bounds__(256) void field_pw16_kernel(FieldArgs a) {
                     pre_prev = pre;
                 } else {
                     f32x16 q;
-                    ph = tile_kc<KCM, 1>(unit_begin(0), m, ph, lane, [&](int c) { q[c] = fr[c] * pre[c]; });
+                    ph = tile_kc<KCM, 1>(unit_begin(0), m, ph, lane, [&](int c) { q[c] = (fr[c] + k2) * pre[c]; });
                     q_prev = q;
                 }
                 ph_prev = ph;
@@ -518,7 +522,7 @@ __global__ void pw16_consts_kernel(PwConstArgs a) {
             const int q = i - 256, l = q / (3 * a.H), r = q - l * 3 * a.H, kind = r / a.H, ch = r - kind * a.H;
             const double is = (double)a.inv_s[1 + 3 * l + kind];
             if (kind == 0) v = (float)((double)a.b[l][ch] / is);
-            else if (kind == 1) v = (float)(((double)a.bm2[(size_t)l * a.H + ch] + 2.0) / is);       // 15 fr + 30 = 15 (fr + 2)
+            else if (kind == 1) v = (float)((double)a.bm2[(size_t)l * a.H + ch] / is);
             else v = (float)((double)a.bm2[(size_t)(a.L + l) * a.H + ch] / is);
         } else if (i < 256 + LH3 + 4) {
             v = a.b_head[i - 256 - LH3];
