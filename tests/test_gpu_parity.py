@@ -1490,6 +1490,60 @@ def test_per_point_film_is_deterministic_over_many_launches(dev, precision):
                 assert (a_ - b_).norm() <= 1e-5 * b_.norm() + 1e-30, (it, float((a_ - b_).norm() / b_.norm()))
 
 
+def test_per_point_film_backward_does_not_depend_on_the_chunking(dev, monkeypatch):
+    """The half-precision backward of the per-point FiLM family over three images: kept activations (one chunk), re-computed activations in
+    one chunk, and re-computed image by image (cnerf_render_backward's chunk loop: per-chunk image offsets of cameras, draws, saved
+    rgb_sigma, activation / gradient buffers) give the same gradients -- parameter gradients to the order of fp32 atomics, and to the order of
+    the per-slab fp16 scales (sampled per chunk), i.e. 1e-3 relative L2."""
+    import cnerf_amd
+    from cnerf_amd import ops
+    from cnerf_amd.generators import ImplicitGenerator3d
+    B, R, S, V = 3, 9, 13, 8
+    torch.manual_seed(5)
+    gen = ImplicitGenerator3d("TALLSIREN", 32, 3, 4, 128).to(dev)
+    gen.set_device(dev)
+    gen.siren.precision, gen.siren.backward_precision = "fp16x3", "fp16"
+    gen.train()
+    with torch.no_grad():
+        gen.siren.final_layer.weight[3] *= 20
+    fvol = torch.randn(B, 32, V, V, V, device=dev) * 0.5
+    cam = torch.eye(4, device=dev).unsqueeze(0).repeat(B, 1, 1).contiguous()
+    cam[:, 2, 3] = -1.0
+    cam[1, 0, 3], cam[2, 1, 3] = 0.1, -0.1                       # different cameras per image: a wrong per-chunk offset shows
+    rng = {"u_strat": torch.rand(B, R * R, S, device=dev), "u_fine": torch.rand(B, R * R, S, device=dev)}
+
+    def grads():
+        fv = fvol.clone().requires_grad_(True)
+        for p_ in gen.parameters():
+            p_.grad = None
+        px, dp = gen(fv, cam, R, 49.13, 0.25, 1.95, S, True, clamp_mode="softplus", nerf_noise=0.0, white_back=True, _rng=rng)
+        ((px * torch.arange(1, B + 1, device=dev).view(B, 1, 1, 1)).square().mean() + dp.mean()).backward()
+        return [fv.grad.clone()] + [p_.grad.clone() for p_ in gen.parameters()]
+
+    kept = grads()
+    monkeypatch.setattr(ops, "resident_act16", lambda *a, **k: None)
+    one_chunk = grads()
+    real_chunk = ops.backward_chunk
+    seen = []
+
+    def by_image(cfg, code, nb_max, have_act16, d):
+        need = C.c_size_t(0)
+        L.check(L.lib().cnerf_backward_workspace_bytes(C.byref(cfg), code, 1, 0, C.byref(need)), "cnerf_backward_workspace_bytes")
+        seen.append(nb_max)
+        return 1, need.value
+    import ctypes as C
+    L = cnerf_amd._lib
+    monkeypatch.setattr(ops, "backward_chunk", by_image)
+    chunked = grads()
+    assert seen == [B]
+    monkeypatch.setattr(ops, "backward_chunk", real_chunk)
+    for a_, b_, c_ in zip(kept, one_chunk, chunked):
+        n = a_.norm().item()
+        assert n > 0
+        assert (a_ - b_).norm().item() <= 1e-5 * n, ((a_ - b_).norm().item() / n)
+        assert (a_ - c_).norm().item() <= 1e-3 * n, ((a_ - c_).norm().item() / n)
+
+
 @pytest.mark.parametrize("precision", ["fp32", "fp16x3"])
 def test_config4_per_gpu_batch_is_batch_invariant(dev, precision):
     """BASELINE config 4's per-GPU workload -- 8 images of 128x128 rays x (64 + 64) samples, 64^3 volumes, hidden 256, what bench.py
