@@ -137,50 +137,36 @@ __device__ __forceinline__ void film_pair(const f32x16& q, const f32x16& ph, flo
     split_into(out2, r, v0, v1);
 }
 
-// Activation-storing forward of the half-precision backward (chain_pw16.hip): per layer and point, fp16:
-//   y = sin(arg)                     TB16 (bwd16.hpp): the X operand of the next layer's weight gradient
-//   cos(arg), cos(arg) f, cos(arg) 15 pre     COS16 fragment-major, three slabs per layer: d arg / d (phase, pre, raw frequency output)
-//                                    already multiplied into the cosine -- the chain is three multiplies per element
-// and per point the largest |stored derivative| of the layer (fp32): the chain scales its fp16 operands from it before they exist.
+// Activation-storing forward of the half-precision backward (chain_pw16.hip): per layer and point, fp16, y = sin(arg) as TB16 (bwd16.hpp: the X
+// operand of the next layer's weight gradient) and cos(arg) as a COS16 slab (fragment-major).  The other two derivative rows the chain
+// multiplies by, cos f and cos 15 pre, come from pw_deriv_kernel below: formed here they need accf and accp of the previous tile next to accph
+// and the accumulator being filled, which this kernel's register file does not have (337 spilled registers, 38 ms per launch against 16 plain).
 struct PwStore {
     _Float16* blk_h;       // y_l: the lane's row in channel tile 0 of the slab (+ 4 h)
     _Float16* blk_c;       // cos: fragment (tile, t = 0, quad 0, lane) of slab 3 l
-    size_t cslab;          // fp16 elements per COS16 slab
-    float kf, kp, k2;      // accf + k2 -> f (x kf), accp -> 15 pre (x kp)
-    float amax;
-    float s[2], c[2], cf[2], cp[2];     // the first pair of a quad, held until the second arrives
+    float s[2], c[2];      // the first pair of a quad, held until the second arrives
     bool live;
 };
 
-__device__ __forceinline__ void film_pair_store(const f32x16& fr, const f32x16& pre, const f32x16& ph, float c1, float c2, int t, int r, Split2* out2,
-                                                PwStore& st) {
-    float sn[2], cs[2], cf[2], cp[2];
+// the plain epilogue plus the cosine; y and cos(arg) leave quad by quad
+__device__ __forceinline__ void film_pair_store(const f32x16& q, const f32x16& ph, float c1, float c2, int t, int r, Split2* out2, PwStore& st) {
+    float sn[2], cs[2];
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
-        const float fa = fr[r + e] + st.k2;
-        const float q = fa * pre[r + e];
-        const float u = __builtin_fmaf(q, c1, ph[r + e] * c2);
+        const float u = __builtin_fmaf(q[r + e], c1, ph[r + e] * c2);
         const float a = u - __builtin_rintf(u);
         sn[e] = __builtin_amdgcn_sinf(a);
         cs[e] = __builtin_amdgcn_cosf(a);
-        cf[e] = __builtin_amdgcn_fmed3f(cs[e] * (fa * st.kf), -65504.0f, 65504.0f);
-        cp[e] = __builtin_amdgcn_fmed3f(cs[e] * (pre[r + e] * st.kp), -65504.0f, 65504.0f);
-        st.amax = fmaxf(st.amax, fmaxf(fabsf(cf[e]), fabsf(cp[e])));
     }
     if ((r & 2) == 0) {
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             st.s[e] = sn[e];
             st.c[e] = cs[e];
-            st.cf[e] = cf[e];
-            st.cp[e] = cp[e];
         }
     } else if (st.live) {
         *reinterpret_cast<u32x2_*>(st.blk_h + t * 1024 + 8 * (r >> 2)) = u32x2_{pk_f16(st.s[0], st.s[1]), pk_f16(sn[0], sn[1])};
-        _Float16* cq = st.blk_c + (size_t)(t * 4 + (r >> 2)) * 256;
-        *reinterpret_cast<u32x2_*>(cq) = u32x2_{pk_f16(st.c[0], st.c[1]), pk_f16(cs[0], cs[1])};
-        *reinterpret_cast<u32x2_*>(cq + st.cslab) = u32x2_{pk_f16(st.cf[0], st.cf[1]), pk_f16(cf[0], cf[1])};
-        *reinterpret_cast<u32x2_*>(cq + 2 * st.cslab) = u32x2_{pk_f16(st.cp[0], st.cp[1]), pk_f16(cp[0], cp[1])};
+        *reinterpret_cast<u32x2_*>(st.blk_c + (size_t)(t * 4 + (r >> 2)) * 256) = u32x2_{pk_f16(st.c[0], st.c[1]), pk_f16(cs[0], cs[1])};
     }
     split_into(out2, r, sn[0], sn[1]);
 }
@@ -206,7 +192,7 @@ struct LaterLayer { static constexpr bool value = false; };
 // Constants in LDS (a.bias, written by pw16_consts_kernel):  bm1 S (256) | per layer: b_l S_pre, bm2 S_f, bm2 S_ph (3 H) | head bias (4)
 // | 1 / S of Wm1, 1 / S of the head, per layer c1, c2, 15 / S_f, 15 / S_pre | the raw 1 / S and max|W| slots of the packing (unused here)
 // STORE: act_feat = TB16 (tiles, 2, 32, 32): the looked-up feature, the position; act_h = L slabs y_l (tiles, NT, 32, 32) then m (tiles, 8,
-// 32, 32); act_c = 3 L COS16 slabs; act_amax = (L, tiles * 32) floats.
+// 32, 32); act_c = 3 L COS16 slabs of which this kernel writes cos(arg) (slab 3 l) -- pw_deriv_kernel fills the other two and act_amax.
 template <int NT, bool STORE>
 __global__ __launch_bounds__(256) void field_pw16_kernel(FieldArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -265,11 +251,11 @@ __global__ __launch_bounds__(256) void field_pw16_kernel(FieldArgs a) {
     // Every wave, at the start of every unit: its share of the unit's copy has landed.  The copy of unit k is requested two units
     // earlier (three slots); LDS-DMA is counted by vmcnt, which retires in order, and the wait is written out: at most N
     // operations may stay in flight, N = a lower bound on what the wave has issued since that request -- the copy instructions of unit
-    // k + 1 (>= PWMIN) and, in the activation-storing forward, the `stores` of the epilogue in between (16 per output tile: 4 quads x
-    // {y, cos, cos f, cos 15 pre}; an idle wave stores nothing).  The barrier orders LDS only: the stores stay in flight across it.
+    // k + 1 (>= PWMIN) and, in the activation-storing forward, the `stores` of the epilogue in between (8 per output tile: 4 quads x
+    // {y, cos}; an idle wave stores nothing).  The barrier orders LDS only: the stores stay in flight across it.
     bool store_live = false;
     auto unit_begin = [&](int stores) -> const f16x8* {
-        if (STORE && store_live && stores >= 16) wait_vmcnt<16 + PWMIN>();
+        if (STORE && store_live && stores >= 8) wait_vmcnt<8 + PWMIN>();
         else wait_vmcnt<PWMIN>();
         lds_only_barrier();
         dma_next();
@@ -295,7 +281,6 @@ __global__ __launch_bounds__(256) void field_pw16_kernel(FieldArgs a) {
         PwStore st;
         st.live = STORE && tile_in_image < a.tiles_per_image;
         store_live = st.live;
-        st.cslab = slab16;
         st.blk_h = STORE ? reinterpret_cast<_Float16*>(a.act_h) + ((size_t)tile_T * NT * 32 + j) * 32 + 4 * h : nullptr;
         st.blk_c = STORE ? reinterpret_cast<_Float16*>(a.act_c) + ((size_t)tile_T * NT * 256 + lane) * 4 : nullptr;
 
@@ -379,20 +364,14 @@ __global__ __launch_bounds__(256) void field_pw16_kernel(FieldArgs a) {
             const float* ci = c_lay + (size_t)l * 3 * H;              // starting values: pre, fr, ph
             const float c1 = c_scal[2 + 4 * l], c2 = c_scal[3 + 4 * l];
             const float k2 = 30.0f / c_scal[4 + 4 * l];          // 2 S_f (a power of two): 15 fr + 30 = 15 (fr + 2), added to the finished accumulator
-            if (STORE) {
-                st.kf = c_scal[4 + 4 * l];
-                st.k2 = k2;
-                st.kp = c_scal[5 + 4 * l];
-                st.amax = 1.0f;                        // |cos| <= 1
-            }
-            f32x16 q_prev, ph_prev, pre_prev;          // (STORE: q_prev holds accf, not accf accp)
+            f32x16 q_prev, ph_prev;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 f32x16 fr = load_chan16(ci + H, t, h);
-                // (t = 0 of a later layer: the previous layer's last epilogue, 16 stores, sits in the interval before this one)
-                fr = tile_kc<KCM, 6>(unit_begin((t == 0 && !FIRST) ? 16 : 0), m, fr, lane, [&](int c) {
+                // (stores since the request of this unit's copy, two units ago: none -- the epilogue of tile t-1, 8 stores, rides under THIS unit)
+                fr = tile_kc<KCM, 6>(unit_begin(0), m, fr, lane, [&](int c) {
                     if (t > 0 && (c & 1)) {
-                        if constexpr (STORE) film_pair_store(q_prev, pre_prev, ph_prev, c1, c2, t - 1, c - 1, &out[2 * (t - 1)], st);
+                        if constexpr (STORE) film_pair_store(q_prev, ph_prev, c1, c2, t - 1, c - 1, &out[2 * (t - 1)], st);
                         else film_pair(q_prev, ph_prev, c1, c2, c - 1, &out[2 * (t - 1)]);
                     }
                 });
@@ -401,28 +380,20 @@ __global__ __launch_bounds__(256) void field_pw16_kernel(FieldArgs a) {
                     pre = acc0[t];
                 } else {
                     pre = load_chan16(ci, t, h);
-                    pre = tile_kc<KCH, 0>(unit_begin(t > 0 ? 16 : 0), in, pre, lane, [](int) {});        // (tile t-1's epilogue rode under fr_t)
+                    pre = tile_kc<KCH, 0>(unit_begin(t > 0 ? 8 : 0), in, pre, lane, [](int) {});        // (tile t-1's epilogue rode under fr_t: 8 stores)
                 }
                 f32x16 ph = load_chan16(ci + 2 * H, t, h);
-                if constexpr (STORE) {
-                    ph = tile_kc<KCM, 0>(unit_begin(t > 0 ? 16 : 0), m, ph, lane, [](int) {});
-                    q_prev = fr;
-                    pre_prev = pre;
-                } else {
-                    f32x16 q;
-                    ph = tile_kc<KCM, 1>(unit_begin(0), m, ph, lane, [&](int c) { q[c] = (fr[c] + k2) * pre[c]; });
-                    q_prev = q;
-                }
+                f32x16 q;
+                ph = tile_kc<KCM, 1>(unit_begin(t > 0 ? 8 : 0), m, ph, lane, [&](int c) { q[c] = (fr[c] + k2) * pre[c]; });
+                q_prev = q;
                 ph_prev = ph;
             }
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
-                if constexpr (STORE) film_pair_store(q_prev, pre_prev, ph_prev, c1, c2, NT - 1, r, &out[2 * (NT - 1)], st);
+                if constexpr (STORE) film_pair_store(q_prev, ph_prev, c1, c2, NT - 1, r, &out[2 * (NT - 1)], st);
                 else film_pair(q_prev, ph_prev, c1, c2, r, &out[2 * (NT - 1)]);
             }
             if (STORE) {
-                const float am = fmaxf(st.amax, __shfl_xor(st.amax, 32, WAVE));       // the two lane halves hold the two halves of a point's channels
-                if (st.live && h == 0) a.act_amax[((size_t)l * a.total_tiles + tile_T) * 32 + j] = am;
                 st.blk_h += slab16;
                 st.blk_c += 3 * slab16;
             }
@@ -435,7 +406,7 @@ __global__ __launch_bounds__(256) void field_pw16_kernel(FieldArgs a) {
         }
         // ---- head -------------------------------------------------------------------------------------------------------------
         {
-            const f16x8* unit = unit_begin(16);                  // (the last layer's last epilogue sits in the interval before this one)
+            const f16x8* unit = unit_begin(8);                   // (the last layer's last epilogue sits in the interval before this one)
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
@@ -459,6 +430,237 @@ __global__ __launch_bounds__(256) void field_pw16_kernel(FieldArgs a) {
     __syncthreads();                                                 // after the block has given its LDS back
 }
 
+#if CNERF_H3_PARTS == 2
+// ---------------------------------------------------------------------------------------------------------------
+// pw_deriv_kernel: the two derivative rows the storing forward leaves out -- cos(arg) f and cos(arg) 15 pre per layer and point (COS16 slabs
+// 3 l + 1, 3 l + 2) and the per-point maxima the chain scales its operands from -- out of what that forward stored: m and y_{l-1} (TB16
+// rows, loaded straight into MFMA B fragments: a lane's eight channels of a k-chunk are two 8-byte pieces of its point's row) and cos(arg).
+// One MFMA per 16 k-values on the LEADING fp16 part of the forward's own two-part weight stream (the hi pieces of a unit are every other
+// KiB; same scales, same starting values): f and 15 pre are derivative factors about to be rounded to fp16, and the operands they come
+// from are fp16 here (relative 6e-4 on 15 pre, 1e-4 on f).  Units used per tile: W_0 | layer 0: fr_t | layers >= 1: fr_t, pre_t; the
+// epilogue of tile t-1 rides under fr_t.  HBM-bound: 8.5 KiB read + 8 KiB written per point and 8 layers.
+// ---------------------------------------------------------------------------------------------------------------
+template <int KC, typename PerChunk>
+__device__ __forceinline__ f32x16 tile_hi(const f16x8* lds_tile, const u32x4* x, f32x16 acc, int lane, PerChunk per_chunk) {
+    f16x8 ring[2] = {lds_tile[lane], lds_tile[64 + lane]};
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+        const f16x8 aw = ring[c & 1];
+        if (c + 2 < KC) ring[c & 1] = lds_tile[(c + 2) * 64 + lane];
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(aw, __builtin_bit_cast(f16x8, x[c]), acc, 0, 0, 0);
+        per_chunk(c);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    return acc;
+}
+
+// B fragments of a point tile out of a TB16 matrix with CT channel tiles: chunk c = channels 16 c + 8 (jj >> 2) + 4 h + (jj & 3) of the lane's point
+template <int NCH>
+__device__ __forceinline__ void load_frags(const _Float16* row, int h, u32x4* x) {       // row = element (tile, channel tile 0, point j, 0)
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const _Float16* p = row + (c >> 1) * 1024 + 16 * (c & 1) + 4 * h;
+        const u32x2_ lo = *reinterpret_cast<const u32x2_*>(p), hi = *reinterpret_cast<const u32x2_*>(p + 8);
+        x[c] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+    }
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void pw_deriv_kernel(FieldArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int H = NT * 32;
+    constexpr int KCH = 2 * NT;
+    constexpr int SLOT_FR = KCM * 64;                                // hi pieces only: at most 16 KiB per unit
+    constexpr int SLOTS = 3;
+    constexpr int PWMIN = KCH / 4;                                   // copy instructions per wave and unit: at least this many (KCH <= KCM)
+    constexpr int CD = NT < 4 ? NT : 4;                              // cos(arg) rows: this many output tiles ahead (NT % CD == 0: the slot of a
+                                                                     // tile is a compile-time number)
+    f16x8* lds = reinterpret_cast<f16x8*>(smem);
+    float* lds_c = reinterpret_cast<float*>(smem + SLOTS * (size_t)SLOT_FR * 16);
+    const int L = a.L;
+    const float* c_lay = lds_c + 256;
+    const float* c_scal = c_lay + (size_t)3 * L * H + 4;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int j = lane & 31, h = lane >> 5;
+    const long long G = (a.tiles_per_image + 3) / 4;
+    const long long total_groups = (a.total_tiles / a.tiles_per_image) * G;
+    const int nblk = gridDim.x;
+    const int cls = blockIdx.x & 7, idx_in_cls = blockIdx.x >> 3;
+    const int blk_per_cls = (nblk + 7 - cls) / 8;
+    const long long g_begin = total_groups * cls / 8 + idx_in_cls, g_end = total_groups * (cls + 1) / 8;
+    if (g_begin >= g_end) return;
+
+    // the used units of a tile and where their hi pieces start in the two-part stream (1-KiB pieces; a unit of n k-chunk fragments is 2 n pieces)
+    const int n_used = 1 + NT + (L - 1) * 2 * NT;
+    const f16x8* w_units = reinterpret_cast<const f16x8*>(a.packed);
+    int dma_k = 0, dma_slot = 0, use_slot = 0;
+    auto dma_next = [&]() {
+        const int k = dma_k;
+        long long piece;                                             // first piece of the unit
+        bool big = true;
+        if (k == 0) {
+            piece = 32;                                              // W_0, behind Wm1 (8 tiles x 2 chunks x 2 parts)
+            big = false;
+        } else if (k <= NT) {
+            piece = 32 + 4 * NT + (long long)(k - 1) * 64;           // layer 0: per tile [fr | ph]
+        } else {
+            const int kk = k - 1 - NT, l1 = kk / (2 * NT), r = kk - l1 * 2 * NT, t = r >> 1;
+            piece = 32 + 4 * NT + (long long)NT * 64 + ((long long)l1 * NT + t) * (64 + 4 * NT) + ((r & 1) ? 32 : 0);   // per tile [fr | W_l | ph]
+            big = (r & 1) == 0;
+        }
+        const f16x8* src = w_units + piece * 64 + lane;             // hi piece i of the unit: 2 i KiB further on
+        f16x8* dst = lds + dma_slot * SLOT_FR;
+        if (big) {
+#pragma unroll
+            for (int q = 0; q < KCM / 4; ++q) {
+                const int i = wave_u * (KCM / 4) + q;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)i * 128),
+                                                 (__attribute__((address_space(3))) void*)(dst + i * 64), 16, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < KCH / 4; ++q) {
+                const int i = wave_u * (KCH / 4) + q;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)i * 128),
+                                                 (__attribute__((address_space(3))) void*)(dst + i * 64), 16, 0, 0);
+            }
+        }
+        dma_k = dma_k + 1 == n_used ? 0 : dma_k + 1;
+        dma_slot = dma_slot == SLOTS - 1 ? 0 : dma_slot + 1;
+    };
+    // counted wait as in the forward: `younger` = vector-memory operations issued in the two intervals before (12 per epilogue: 4 loads, 8 stores)
+    auto unit_begin = [&](int younger) -> const f16x8* {
+        if (younger >= 12) wait_vmcnt<12 + PWMIN>();
+        else wait_vmcnt<PWMIN>();
+        lds_only_barrier();
+        dma_next();
+        const f16x8* unit = lds + use_slot * SLOT_FR;
+        use_slot = use_slot == SLOTS - 1 ? 0 : use_slot + 1;
+        return unit;
+    };
+    for (int i = threadIdx.x; i < a.bias_floats; i += 256) lds_c[i] = a.bias[i];
+    dma_next();
+    dma_next();
+
+    for (long long g = g_begin; g < g_end; g += blk_per_cls) {
+        const int b = (int)(g / G);
+        const long long tile_in_image = (g - (long long)b * G) * 4 + wave;
+        const bool live = tile_in_image < a.tiles_per_image;
+        const long long n = tile_in_image * 32 + j;
+        const bool valid = live && n < a.n_per_image;
+        const long long nn = n < a.n_per_image ? n : a.n_per_image - 1;
+        const long long tile_T = (long long)b * a.tiles_per_image + (live ? tile_in_image : a.tiles_per_image - 1);   // (idle waves re-read a real tile, store nothing)
+        const size_t slab16 = (size_t)a.total_tiles * NT * 1024;
+        const _Float16* act_h = reinterpret_cast<const _Float16*>(a.act_h);
+        _Float16* act_c = reinterpret_cast<_Float16*>(a.act_c);
+        u32x4 m[KCM];
+        load_frags<KCM>(act_h + (size_t)L * slab16 + ((size_t)tile_T * 8 * 32 + j) * 32, h, m);
+        float px, py, pz;
+        tile_point(a, b, nn, valid, h, false, px, py, pz);
+        // cos(arg) rows, CD output tiles ahead over the linear sequence (layer, tile)
+        f16x4 cosr[CD][4];
+        auto fetch_cos = [&](int l, int t, int slot) {
+            const _Float16* src = act_c + (size_t)(3 * l) * slab16 + (((size_t)tile_T * NT + t) * 256 + lane) * 4;
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) cosr[slot][gq] = *reinterpret_cast<const f16x4*>(src + gq * 256);
+        };
+        auto prefetch_after = [&](int l, int t) {
+            int tn = t + CD, ln = l;
+            while (tn >= NT) {
+                tn -= NT;
+                ln += 1;
+            }
+            if (ln >= L) {
+                ln = L - 1;
+                tn = NT - 1;
+            }
+            fetch_cos(ln, tn, t % CD);
+        };
+#pragma unroll
+        for (int t = 0; t < CD; ++t) fetch_cos(t / NT < L ? t / NT : L - 1, t % NT, t);
+
+        // layer 0 reads the position
+        f32x16 acc0[NT];
+        {
+            const f16x8* unit = unit_begin(0);
+            float fv[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) fv[r] = 0.0f;
+            if (h == 0) {
+                fv[0] = px;
+                fv[1] = py;
+                fv[2] = pz;
+            }
+            u32x4 f2[2];
+            f2[0] = u32x4{pk_f16(fv[0], fv[1]), pk_f16(fv[2], fv[3]), 0u, 0u};
+            f2[1] = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc0[t] = load_chan16(c_lay, t, h);
+#pragma unroll
+            for (int q = 0; q < 2 * NT; ++q)        // k_outer unit: fragment pair q = 2 t + c
+                acc0[q >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(unit[q * 64 + lane], __builtin_bit_cast(f16x8, f2[q & 1]), acc0[q >> 1], 0, 0, 0);
+        }
+        u32x4 x[KCH];
+        auto layer = [&](auto first_tag, int l) {
+            constexpr bool FIRST = decltype(first_tag)::value;
+            const float* ci = c_lay + (size_t)l * 3 * H;
+            const float kf = c_scal[4 + 4 * l], kp = c_scal[5 + 4 * l];
+            const float k2 = 30.0f / kf;
+            float amax = 1.0f;                                       // |cos| <= 1
+            _Float16* dst = act_c + (size_t)(3 * l + 1) * slab16 + ((size_t)tile_T * NT * 256 + lane) * 4;
+            f32x16 fr_prev, pre_prev;
+            auto epi_quad = [&](const f32x16& fr, const f32x16& pre, int t, int gq) {       // quad gq of tile t: 4 consecutive channels
+                float cf[4], cp[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float c = (float)cosr[t % CD][gq][e];
+                    cf[e] = __builtin_amdgcn_fmed3f(c * ((fr[4 * gq + e] + k2) * kf), -65504.0f, 65504.0f);
+                    cp[e] = __builtin_amdgcn_fmed3f(c * (pre[4 * gq + e] * kp), -65504.0f, 65504.0f);
+                    amax = fmaxf(amax, fmaxf(fabsf(cf[e]), fabsf(cp[e])));
+                }
+                if (live) {
+                    _Float16* d = dst + (size_t)(t * 4 + gq) * 256;
+                    *reinterpret_cast<u32x2_*>(d) = u32x2_{pk_f16(cf[0], cf[1]), pk_f16(cf[2], cf[3])};
+                    *reinterpret_cast<u32x2_*>(d + slab16) = u32x2_{pk_f16(cp[0], cp[1]), pk_f16(cp[2], cp[3])};
+                }
+            };
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                f32x16 fr = load_chan16(ci + H, t, h);
+                // (the two intervals before: pre_{t-1} none, fr_{t-1} the epilogue of tile t-2 -- 12 operations)
+                fr = tile_hi<KCM>(unit_begin(t >= 2 ? 12 : 0), m, fr, lane, [&](int c) {
+                    if (t > 0 && (c & 3) == 3) epi_quad(fr_prev, pre_prev, t - 1, c >> 2);
+                });
+                if (t > 0) prefetch_after(l, t - 1);
+                f32x16 pre;
+                if constexpr (FIRST) {
+                    pre = acc0[t];
+                } else {
+                    pre = load_chan16(ci, t, h);
+                    pre = tile_hi<KCH>(unit_begin(t >= 1 ? 12 : 0), x, pre, lane, [](int) {});      // (fr_t held the epilogue of tile t-1)
+                }
+                fr_prev = fr;
+                pre_prev = pre;
+            }
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) epi_quad(fr_prev, pre_prev, NT - 1, gq);
+            prefetch_after(l, NT - 1);
+            const float am = fmaxf(amax, __shfl_xor(amax, 32, WAVE));
+            if (live && h == 0) a.act_amax[((size_t)l * a.total_tiles + tile_T) * 32 + j] = am;
+        };
+        layer(FirstLayer{}, 0);
+        for (int l = 1; l < L; ++l) {
+            load_frags<KCH>(act_h + (size_t)(l - 1) * slab16 + ((size_t)tile_T * NT * 32 + j) * 32, h, x);
+            layer(LaterLayer{}, l);
+        }
+    }
+    wait_vmcnt<0>();
+    __syncthreads();
+}
+#endif
+
 constexpr size_t LDS_LIMIT = 160 * 1024;
 
 template <int NT, bool STORE>
@@ -480,7 +682,7 @@ static hipError_t launch_inst(const FieldArgs& a, hipStream_t stream) {
 static hipError_t field_impl(const FieldArgs& a, int H, hipStream_t stream) {
     if (a.n_in != 1 || a.in_level[0] < 0 || a.L < 1) return hipErrorInvalidValue;      // one 32-channel volume tile
     const bool store = a.act_h != nullptr;             // activation-storing forward of the half-precision backward (fp16 tile blocks)
-    if (store && (!a.act_tb16 || !a.act_feat || !a.act_c || !a.act_amax)) return hipErrorInvalidValue;
+    if (store && (PARTS != 2 || !a.act_tb16 || !a.act_feat || !a.act_c || !a.act_amax)) return hipErrorInvalidValue;
     switch (H / 32) {
         case 2: return store ? launch_inst<2, true>(a, stream) : launch_inst<2, false>(a, stream);
         case 4: return store ? launch_inst<4, true>(a, stream) : launch_inst<4, false>(a, stream);
@@ -489,10 +691,40 @@ static hipError_t field_impl(const FieldArgs& a, int H, hipStream_t stream) {
     }
 }
 
+#if CNERF_H3_PARTS == 2
+template <int NT>
+static hipError_t launch_deriv_inst(const FieldArgs& a, hipStream_t stream) {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+    const size_t lds_bytes = 3 * (size_t)KCM * 1024 + (size_t)a.bias_floats * 4;
+    if (lds_bytes > LDS_LIMIT) return hipErrorInvalidValue;
+    if (hipError_t e = hipFuncSetAttribute((const void*)pw_deriv_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT)) return e;
+    const long long want = (a.total_tiles / a.tiles_per_image) * ((a.tiles_per_image + 3) / 4);
+    int blocks = (int)(want < cus ? want : cus);
+    if (blocks < 8) blocks = 8;
+    blocks = (blocks + 7) / 8 * 8;
+    hipLaunchKernelGGL((pw_deriv_kernel<NT>), dim3(blocks), dim3(256), lds_bytes, stream, a);
+    return hipGetLastError();
+}
+#endif
+
 }  // namespace pw
 }  // namespace H3_NS
 
-hipError_t PW_LAUNCH_FIELD(const FieldArgs& a, int H, hipStream_t stream) { return H3_NS::pw::field_impl(a, H, stream); }
+hipError_t PW_LAUNCH_FIELD(const FieldArgs& a, int H, hipStream_t stream) {
+    if (hipError_t e = H3_NS::pw::field_impl(a, H, stream)) return e;
+#if CNERF_H3_PARTS == 2
+    if (a.act_h) {      // activation-storing forward: the derivative rows the field kernel leaves out (same stream: ordered behind it)
+        switch (H / 32) {
+            case 2: return H3_NS::pw::launch_deriv_inst<2>(a, stream);
+            case 4: return H3_NS::pw::launch_deriv_inst<4>(a, stream);
+            case 8: return H3_NS::pw::launch_deriv_inst<8>(a, stream);
+        }
+    }
+#endif
+    return hipSuccess;
+}
 
 #if CNERF_H3_PARTS == 2
 // ---------------------------------------------------------------------------------------------------------------
