@@ -1154,8 +1154,8 @@ int cnerf_render_backward(const cnerf_cfg* cfg, int32_t bprec, int32_t cnt_max, 
                 PwChainBuffers cb{base16, base16 + cl.head_off, (const float*)(base16 + cl.winv_off), (const float*)(base16 + cl.anorm_off), scales, a_c,
                                   a_amax, a_h + (size_t)Lc * slabH, a_g, a_go, gmax, nullptr};
                 const long long groups = (long long)cnt * ((tpi + 3) / 4);
-                long long step = groups / 2048;                       // dry-run sampling: every 16th tile group once there are plenty
-                step = step < 1 ? 1 : (step > 16 ? 16 : step);
+                long long step = groups / 1024;                       // dry-run sampling: at least 1024 tile groups (131 k points), every 32nd at most
+                step = step < 1 ? 1 : (step > 32 ? 32 : step);
                 if (hipError_t e = launch_chain_pw16(fa, H, cb, 1, (int)step, stream)) return hip_fail(e, "chain_pw16 (dry run)");
                 if (hipError_t e = launch_pow2_scales(gmax, n_slots - 1, scales, stream)) return hip_fail(e, "pow2_scales");
                 cb.sat = saturated;
