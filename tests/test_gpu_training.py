@@ -93,6 +93,31 @@ def test_gan_step_with_the_per_point_film_generator(precisions):
 NORMS = {}
 
 
+def test_no_grad_render_runs_the_plain_forward(monkeypatch):
+    """The D step renders under torch.no_grad() with the generator in training mode and its parameters requiring grad: nothing will
+    back-propagate, so the forward must not keep activations (the activation-storing kernel is 1.5 x the plain one and its buffers are
+    GiBs).  Regression: inside autograd.Function.forward `ctx.needs_input_grad` is True for parameters whatever the grad mode."""
+    import cnerf_amd
+    from cnerf_amd import ops
+    from cnerf_amd.generators import ImplicitGenerator3d
+    dev = torch.device("cuda:0")
+    gen = ImplicitGenerator3d("SHORTSIREN_FG", 32, 32, 4, 64).to(dev)
+    gen.set_device(dev)
+    gen.siren.precision, gen.siren.backward_precision = "fp16x3", "fp16"
+    gen.train()
+    calls = []
+    real = ops.resident_act16
+    monkeypatch.setattr(ops, "resident_act16", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    z = (torch.randn(1, 32, 8, 8, 8, device=dev), torch.randn(1, 32, device=dev))
+    cam = torch.eye(4, device=dev).unsqueeze(0)
+    kw = dict(clamp_mode="relu", nerf_noise=0.0, white_back=True)
+    with torch.no_grad():
+        gen(z, cam, 8, 30.0, 0.5, 1.5, 6, True, **kw)
+    assert calls == []
+    px, _ = gen(z, cam, 8, 30.0, 0.5, 1.5, 6, True, **kw)
+    assert calls == [1] and px.requires_grad
+
+
 def test_gan_step_ddp_one_rank_rccl():
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
