@@ -17,9 +17,10 @@
 //
 // Epilogue.  Every accumulator starts from its bias in accumulator units (S b), and 15 fr + 30 = 15 (fr + 2), so
 //     u = arg / 2 pi = (accf + 2 S_f) accp c1 + accph c2,    c1 = 15 / (2 pi S_f S_pre),  c2 = 1 / (2 pi S_ph)      (per layer, prepared on the device)
-// is an add, two multiplies and one fma per element (the 2 S_f is added to the FINISHED accumulator: started from S_f (bm2 + 2) the 48 partial
-// sums of a product each round at the magnitude of 2 S_f -- rgb of `tallsiren_small` 9.6e-5 from the reference instead of 3e-5), then the exact reduction u - rint(u) and v_sin_f32 (which takes revolutions).  Rounding:
-// the product accf accp and the fma round at the magnitude of the argument like the reference's own freq * x + phase does.
+// is an add, two multiplies and one fma per element (the 2 S_f is added to the FINISHED accumulator: started from S_f (bm2 + 2) the 48
+// partial sums of a product each round at the magnitude of 2 S_f -- rgb of `tallsiren_small` 9.6e-5 from the reference instead of 5.5e-5),
+// then the exact reduction u - rint(u) and v_sin_f32 (which takes revolutions).  Rounding: the product accf accp and the fma round at the
+// magnitude of the argument like the reference's own freq * x + phase does.
 // The epilogue of output tile t-1 runs under the 48 MFMAs of fr_t (always 16 k-chunks: one element pair per two chunks), accf accp
 // under those of ph_t: 9 MFMAs per accumulator register against 3 in field_h3.hip -- the vector work is covered.
 #include "cnerf_dev.hpp"
