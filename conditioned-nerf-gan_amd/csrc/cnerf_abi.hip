@@ -3,6 +3,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "cnerf_kernels.hpp"
@@ -797,12 +798,14 @@ int chain16_layout(const cnerf_cfg* c, Chain16Layout& l) {
 namespace {
 // per-point FiLM family (chain_pw16.hip): [unit stream][head^T: NT fragments x 64 lanes][winv: 2 L + 2][anorm: L + 1][max|W| scratch: 2 L + 2]
 struct PwChainLayout {
-    size_t head_off, winv_off, anorm_off, wmax_off, total;
+    size_t y_off, m_off, head_off, winv_off, anorm_off, wmax_off, total;
 };
 PwChainLayout pw_chain_layout(const cnerf_cfg* c) {
     PwChainLayout l;
     const size_t NT = c->H / 32, L = c->L;
-    l.head_off = align256(pw_chain_units_bytes(c->L, c->H));
+    l.y_off = align256(pw_chain_units_bytes(c->L, c->H));           // (fused stream first, then the two-kernel chain's Y and M streams)
+    l.m_off = l.y_off + align256(pw_chain_split_y_bytes(c->L, c->H));
+    l.head_off = l.m_off + align256(pw_chain_split_m_bytes(c->L, c->H));
     l.winv_off = l.head_off + align256(NT * 1024);
     l.anorm_off = l.winv_off + align256((2 * L + 2) * sizeof(float));
     l.wmax_off = l.anorm_off + align256((L + 1) * sizeof(float));
@@ -835,7 +838,7 @@ int cnerf_pack_field_chain16(const cnerf_cfg* cfg, const cnerf_field_params* p, 
         const PwChainLayout l = pw_chain_layout(cfg);
         char* base = (char*)packed16;
         if (hipError_t e = launch_pack_pw_chain(p, cfg->L, cfg->H, base, base + l.head_off, (float*)(base + l.winv_off), (float*)(base + l.anorm_off),
-                                                (uint32_t*)(base + l.wmax_off), (hipStream_t)stream_))
+                                                (uint32_t*)(base + l.wmax_off), (hipStream_t)stream_, base + l.y_off, base + l.m_off))
             return hip_fail(e, "pack_pw_chain");
         return CNERF_OK;
     }
@@ -968,6 +971,7 @@ struct BackwardLayout {
     size_t gc, gf;                                   // d loss / d rgb_sigma of the coarse / fine samples, whole call
     size_t a_feat, a_h, a_c, a_g, a_go;              // chunk buffers (a_feat / a_h / a_c absent when the forward kept its activations)
     size_t a_amax;                                   // per-point FiLM family: (L, T * 32) floats
+    size_t a_gy;                                     // per-point FiLM family: L TB16 slabs of g_y
     size_t gmax, scales;                             // fp16: sampled maxima (n_mats + 1 uint32), {S, 1/S} pairs (n_mats + 1)
     size_t dwarg, cs, dwh, csh;                      // per-image reductions of one matrix: (cnt, H, 32 * max tiles), (cnt, H), (cnt, 4, H), (cnt, 4)
     size_t total;
@@ -998,8 +1002,9 @@ int backward_layout(const cnerf_cfg* c, int bprec, int cnt, bool have_act16, Bac
         L.a_amax = take(have_act16 ? 0 : Lc * T * 32 * sizeof(float));
         L.a_g = take((3 * Lc * NT + 8) * T * 2048);
         L.a_go = take(T * 2048);
-        L.gmax = take((3 * Lc + 2) * sizeof(uint32_t));
-        L.scales = take(2 * (3 * Lc + 2) * sizeof(float));
+        L.a_gy = take(Lc * NT * T * 2048);                          // two-kernel chain: g_y slabs
+        L.gmax = take((5 * Lc + 2) * sizeof(uint32_t));             // 3 L + 2 sampled maxima, L of g_y, L of the stored derivatives
+        L.scales = take((2 * (4 * Lc + 2) + 2 * Lc) * sizeof(float));   // {S, 1 / S} x (4 L + 2), then per layer {r, To}
         L.dwarg = take((size_t)cnt * 256 * 256 * sizeof(float));
         L.cs = take((size_t)cnt * 256 * sizeof(float));
         L.dwh = take((size_t)cnt * 4 * H * sizeof(float));
@@ -1035,6 +1040,7 @@ int backward_layout(const cnerf_cfg* c, int bprec, int cnt, bool have_act16, Bac
         L.a_go = take(n * 4 * sizeof(float));
     }
     L.a_amax = 0;
+    L.a_gy = 0;
     L.gmax = take((size_t)(L.n_mats + 2) * sizeof(uint32_t));
     L.scales = take((size_t)2 * (L.n_mats + 1) * sizeof(float));
     const size_t kmax = 32 * (size_t)(L.n_in > (int)NT ? L.n_in : (int)NT);
@@ -1145,21 +1151,42 @@ int cnerf_render_backward(const cnerf_cfg* cfg, int32_t bprec, int32_t cnt_max, 
                 }
                 fa.grad_out = g_out + (size_t)b0 * npi * 4;
                 fa.saved_out = s_out + (size_t)b0 * npi * 4;
-                if (hipError_t e = hipMemsetAsync(gmax, 0, (size_t)n_slots * sizeof(uint32_t), stream)) return hip_fail(e, "memset");
+                if (hipError_t e = hipMemsetAsync(gmax, 0, (size_t)(5 * Lc + 2) * sizeof(uint32_t), stream)) return hip_fail(e, "memset");
                 if (hipError_t e = launch_absmax_bits(fa.grad_out, (long long)cnt * npi * 4, gmax + n_slots - 1, stream)) return hip_fail(e, "absmax");
                 if (hipError_t e = launch_pow2_scales(gmax + n_slots - 1, 1, scales + 2 * (n_slots - 1), stream)) return hip_fail(e, "pow2_scales");
                 for (int m = 0; m < n_slots - 1; ++m)
                     if (hipError_t e = launch_fill(scales + 2 * m, 1.0f, 2, stream)) return hip_fail(e, "fill");
                 const size_t slabH = (size_t)T * NT * 2048;            // bytes per (tiles, NT, 32, 32) slab
+                float* lay = scales + 2 * (4 * Lc + 2);
                 PwChainBuffers cb{base16, base16 + cl.head_off, (const float*)(base16 + cl.winv_off), (const float*)(base16 + cl.anorm_off), scales, a_c,
-                                  a_amax, a_h + (size_t)Lc * slabH, a_g, a_go, gmax, nullptr};
+                                  a_amax, a_h + (size_t)Lc * slabH, a_g, a_go, gmax, nullptr,
+                                  base16 + cl.y_off, base16 + cl.m_off, ws + L.a_gy, lay};
                 const long long groups = (long long)cnt * ((tpi + 3) / 4);
                 long long step = groups / 1024;                       // dry-run sampling: at least 1024 tile groups (131 k points), every 32nd at most
                 step = step < 1 ? 1 : (step > 32 ? 32 : step);
-                if (hipError_t e = launch_chain_pw16(fa, H, cb, 1, (int)step, stream)) return hip_fail(e, "chain_pw16 (dry run)");
-                if (hipError_t e = launch_pow2_scales(gmax, n_slots - 1, scales, stream)) return hip_fail(e, "pow2_scales");
-                cb.sat = saturated;
-                if (hipError_t e = launch_chain_pw16(fa, H, cb, 0, 1, stream)) return hip_fail(e, "chain_pw16");
+                static const bool fused = getenv("CNERF_PW_FUSED_CHAIN") != nullptr;      // (A/B switch of the round: the one-kernel chain)
+                if (fused) {
+                    if (hipError_t e = launch_chain_pw16(fa, H, cb, 1, (int)step, stream)) return hip_fail(e, "chain_pw16 (dry run)");
+                    if (hipError_t e = launch_pow2_scales(gmax, n_slots - 1, scales, stream)) return hip_fail(e, "pow2_scales");
+                    cb.sat = saturated;
+                    if (hipError_t e = launch_chain_pw16(fa, H, cb, 0, 1, stream)) return hip_fail(e, "chain_pw16");
+                } else {
+                    // two kernels: g_y through the layer matrices (dry run -> its scales), then the mapping products and the stored slabs
+                    for (int m = 0; m < Lc; ++m)
+                        if (hipError_t e = launch_fill(scales + 2 * (3 * Lc + 2 + m), 1.0f, 2, stream)) return hip_fail(e, "fill");
+                    if (hipError_t e = launch_chain_pre(fa, H, cb, 1, (int)step, stream)) return hip_fail(e, "chain_pre (dry run)");
+                    if (hipError_t e = launch_pow2_scales(gmax + 3 * Lc + 2, Lc, scales + 2 * (3 * Lc + 2), stream)) return hip_fail(e, "pow2_scales");
+                    for (int m = 0; m < Lc; ++m)      // the largest stored derivative of each layer over the chunk's points
+                        if (hipError_t e = launch_absmax_bits(a_amax + (size_t)m * T * 32, T * 32, gmax + 4 * Lc + 2 + m, stream)) return hip_fail(e, "absmax");
+                    if (hipError_t e = launch_pw_split_scales(gmax + 4 * Lc + 2, Lc, scales, lay, stream)) return hip_fail(e, "split_scales");
+                    cb.sat = saturated;
+                    if (hipError_t e = launch_chain_pre(fa, H, cb, 0, 1, stream)) return hip_fail(e, "chain_pre");
+                    cb.sat = nullptr;
+                    if (hipError_t e = launch_pw_gm(fa, H, cb, 1, (int)step, stream)) return hip_fail(e, "pw_gm (dry run)");
+                    if (hipError_t e = launch_pow2_scales(gmax + 3 * Lc, 1, scales + 2 * (3 * Lc), stream)) return hip_fail(e, "pow2_scales");
+                    cb.sat = saturated;
+                    if (hipError_t e = launch_pw_gm(fa, H, cb, 0, 1, stream)) return hip_fail(e, "pw_gm");
+                }
                 // one reduction: G (n_rows of slab `slot`) against X (x_ct channel tiles), take k_real columns from column k0 on
                 auto reduce = [&](const void* Gs, int g_ct, int n_rows, int slot, const void* X, int x_ct, int k0, int k_real, float* dW, float* db) -> int {
                     if (hipError_t e = hipMemsetAsync(dwarg, 0, (size_t)cnt * n_rows * 32 * x_ct * sizeof(float), stream)) return hip_fail(e, "memset");

@@ -214,12 +214,22 @@ struct PwChainBuffers {
     const void* m16;          // TB16 (tiles, 8, 32, 32)
     void* g16;                // TB16: 3 L slabs (tiles, NT, 32, 32) then g_mpre (tiles, 8, 32, 32)
     void* go16;
-    unsigned int* gmax;       // dry run: 3 L + 2 maxima
+    unsigned int* gmax;       // dry run: 3 L + 2 maxima (two-kernel chain: + L maxima of g_y)
     unsigned int* sat;
+    // the two-kernel chain (chain_pre_kernel + pw_gm_kernel)
+    const void* units_y;      // Y units
+    const void* units_m;      // M units + Wm1^T
+    void* gy16;               // TB16: L slabs (tiles, NT, 32, 32) of g_y
+    const float* lay;         // per layer {r_l, To_l}
 };
+hipError_t launch_chain_pre(const FieldArgs& f, int H, const PwChainBuffers& c, int dry, int group_step, hipStream_t stream);
+hipError_t launch_pw_gm(const FieldArgs& f, int H, const PwChainBuffers& c, int dry, int group_step, hipStream_t stream);
+hipError_t launch_pw_split_scales(const uint32_t* amaxg_bits, int L, float* scales, float* lay, hipStream_t stream);
+size_t pw_chain_split_y_bytes(int L, int H);
+size_t pw_chain_split_m_bytes(int L, int H);
 hipError_t launch_chain_pw16(const FieldArgs& f, int H, const PwChainBuffers& c, int dry, int group_step, hipStream_t stream);
 size_t pw_chain_units_bytes(int L, int H);
 hipError_t launch_pack_pw_chain(const cnerf_field_params* p, int L, int H, void* units, void* head_t, float* winv, float* anorm, uint32_t* wmax,
-                                hipStream_t stream);
+                                hipStream_t stream, void* units_y = nullptr, void* units_m = nullptr);
 
 }  // namespace cnerf
