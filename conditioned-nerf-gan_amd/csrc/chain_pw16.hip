@@ -10,17 +10,10 @@
 // The weight gradients are reductions over the stored slabs (weight_grad16_kernel): dW_l = g_pre_l^T y_{l-1}, dWm2 = [g_fr | g_ph]^T m,
 // dWm1 = g_mpre^T feat, dW_head = go^T y_{L-1}.
 //
-// One wave per 32-point tile; accumulator registers, converted pairwise, are the next B operands (channel = k) exactly as in the
-// forward kernels.  Per stage (= layer whose quantities are produced, from L-1 down to 0) and 32-channel tile t:
-//     z_t = rows [32 t, 32 t + 32) of W_{l+1}^T g_pre_{l+1}        unit Y(t): KCH k-chunks      (stage L-1: head^T go, from LDS)
-//     epilogue(t): the three products above, stores, fp16 operands of tile t
-//     g_m (8 accumulator tiles, resident for the whole tile) += Wm2^T[.., channels of tile t] (g_fr, g_ph)(t)     unit M(t): 8 x 4 chunks
-// software-pipelined so that epilogue(t) rides under the 32 MFMAs of M(t-1):  Y(0) e(0) | Y(1) M(0)+e(1) | ... | Y(NT-1) M(NT-2)+e(NT-1) | M(NT-1),
-// which is also the order of the packed unit stream.  g_m accumulates across stages whose operand scales differ: at a stage boundary the
-// accumulators are multiplied by the ratio of the two (powers of two: exact).
-// fp16 appears at two conversion points, as in chain16: MFMA B operands carry ONE power-of-two scale per point and stage for all three
-// quantities, fixed before the values exist from  (largest |stored derivative| of the point, kept by the forward) x ||W_{l+1}||_1 x
-// max |g_pre_{l+1}| of the point;  stored slabs carry one scale per slab and call, from the maxima a DRY instantiation samples.
+// Two kernels, each within the register file.  (The first version did all of it in one: 128 resident accumulators of g_m next to two
+// operand arrays, three derivative rows two tiles ahead and the epilogue's three stored quads -- 195 spilled dwords at H = 256, 64 GB of
+// scratch traffic per launch, 31 ms; commit 9b8cfcc has it.)  One wave per 32-point tile, accumulator registers converted pairwise are the
+// next B operands (channel = k) as in the forward kernels, weight units through a three-slot LDS ring by LDS-DMA, counted vmcnt waits.
 #include "bwd16.hpp"
 #include "cnerf_dev.hpp"
 #include "cnerf_kernels.hpp"
@@ -28,23 +21,6 @@
 
 namespace cnerf {
 namespace pwchain {
-
-struct Args {
-    FieldArgs f;              // geometry, tiles, L, flags, the gradient volume, grad_out / saved_out
-    const f16x8* units;       // transposed weight units in consumption order (pack below)
-    const f16x8* head_t;      // head^T fragments (NT x 64 lanes)
-    const float* winv;        // 1 / s: [W_l^T: L (entry 0 unused) | Wm2 pair of layer l: L | Wm1^T | head^T]
-    const float* anorm;       // ||W_l||_1: L (entry 0 unused), then the head's
-    const float* scales;      // {S, 1 / S} x (3 L + 2): per layer (g_pre, g_fr, g_ph), g_mpre, go
-    const _Float16* cos16;    // 3 L COS16 slabs (tiles, NT, 4, 64, 4): per layer cos, cos f, cos 15 pre
-    const float* amax;        // (L, tiles * 32): per point the largest |stored derivative| of the layer (>= 1)
-    const _Float16* m16;      // TB16 (tiles, 8, 32, 32): m
-    _Float16* g16;            // TB16: 3 L slabs (tiles, NT, 32, 32), then g_mpre (tiles, 8, 32, 32)
-    _Float16* go16;           // TB16 (tiles, 1, 32, 32)
-    unsigned int* gmax;       // dry run: bits of the 3 L + 2 sampled maxima (true units)
-    unsigned int* sat;        // chain run, optional: += 1 per (tile, stage) whose stored gradients were clamped to fp16's range
-    int group_step;
-};
 
 __device__ __forceinline__ float pow2_to_2p14(float bound) {     // T = 2^(14 - e), bound = m 2^e, m in [0.5, 1); 0 / denormal / huge -> 1
     const int e = (int)((__float_as_uint(bound) >> 23) & 255u) - 126;
@@ -63,432 +39,24 @@ __device__ __forceinline__ void dma_pieces(const f16x8* __restrict__ src, f16x8*
                                          0, 0);
 }
 
-// per-stage state of the epilogue
-struct Epi {
-    float UT, USpre, USfr, USph;     // accumulator -> operand scale, -> the three stored scales
-    float mpre, mfr, mph;            // running maxima (accumulator units x stored derivative): mpre bounds the next stage's operands
-    float spre[4], sfr[4], sph[4];   // stored quads being assembled
-    float epre, efr, eph;            // operand pairs being assembled
-    _Float16* gdst;                  // g16 row of the lane's point, channel tile 0 of the stage's g_pre slab (+ 4 h)
-    size_t slab;                     // fp16 elements per slab
-    bool live;
-};
-
-// element r of tile t: z -> three stored values, three operand halves
-template <bool DRY>
-__device__ __forceinline__ void epi_element(const f32x16& z, const f16x4 (*cq)[4], int t, int r, Epi& st, u32x4* frag_pre, u32x4* fnew_fr, u32x4* fnew_ph) {
-    const int gq = r >> 2, e = r & 3;
-    const float a = z[r];
-    const float vph = a * (float)cq[0][gq][e], vpre = a * (float)cq[1][gq][e], vfr = a * (float)cq[2][gq][e];
-    st.mpre = fmaxf(st.mpre, fabsf(vpre));
-    st.mfr = fmaxf(st.mfr, fabsf(vfr));
-    st.mph = fmaxf(st.mph, fabsf(vph));
-    if (!DRY) {
-        st.spre[e] = __builtin_amdgcn_fmed3f(vpre * st.USpre, -65504.0f, 65504.0f);
-        st.sfr[e] = __builtin_amdgcn_fmed3f(vfr * st.USfr, -65504.0f, 65504.0f);
-        st.sph[e] = __builtin_amdgcn_fmed3f(vph * st.USph, -65504.0f, 65504.0f);
-        if (e == 3 && st.live) {
-            _Float16* d = st.gdst + t * 1024 + 8 * gq;
-            *reinterpret_cast<u32x2_*>(d) = u32x2_{pk_f16(st.spre[0], st.spre[1]), pk_f16(st.spre[2], st.spre[3])};
-            *reinterpret_cast<u32x2_*>(d + st.slab) = u32x2_{pk_f16(st.sfr[0], st.sfr[1]), pk_f16(st.sfr[2], st.sfr[3])};
-            *reinterpret_cast<u32x2_*>(d + 2 * st.slab) = u32x2_{pk_f16(st.sph[0], st.sph[1]), pk_f16(st.sph[2], st.sph[3])};
-        }
-    }
-    const float opre = vpre * st.UT, ofr = vfr * st.UT, oph = vph * st.UT;
-    if ((r & 1) == 0) {
-        st.epre = opre;
-        st.efr = ofr;
-        st.eph = oph;
-    } else {
-        frag_pre[2 * t + (r >> 3)][(r & 7) >> 1] = pk_f16(st.epre, opre);
-        fnew_fr[r >> 3][(r & 7) >> 1] = pk_f16(st.efr, ofr);
-        fnew_ph[r >> 3][(r & 7) >> 1] = pk_f16(st.eph, oph);
-    }
-}
-
 struct RescaleYes { static constexpr bool value = true; };
 struct RescaleNo { static constexpr bool value = false; };
 
-template <int NT, bool DRY>
-__global__ __launch_bounds__(256) void chain_pw16_kernel(Args A) {
-    extern __shared__ __attribute__((aligned(16))) char smem_p[];
-    const FieldArgs& a = A.f;
-    constexpr int KCH = 2 * NT;
-    constexpr int P_M = 32, P_Y = KCH, P_W1 = 16;       // 1-KiB pieces per unit kind
-    constexpr int SLOT_FR = 32 * 64;                    // fragments per LDS slot
-    constexpr int CD = 2;                               // prefetch distance of the derivative rows, in tiles
-    constexpr int SLOTS = 3;                            // weight units in LDS: one being read, two being copied
-    f16x8* lds_units = reinterpret_cast<f16x8*>(smem_p);
-    f16x8* lds_head = lds_units + SLOTS * SLOT_FR;                              // NT * 64 fragments
-    float* s_g = reinterpret_cast<float*>(lds_head + NT * 64);                  // [4][32][33] scatter transpose
-    int* s_base = reinterpret_cast<int*>(s_g + 4 * 32 * 33);                    // [4][32][8]
-    float* s_w = reinterpret_cast<float*>(s_base + 4 * 32 * 8);                 // [4][32][8]
-    const int L = a.L;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    const int j = lane & 31, h = lane >> 5;
-
-    const long long G = (a.tiles_per_image + 3) / 4;
-    const long long total_groups = (a.total_tiles / a.tiles_per_image) * G;
-    const int nblk = gridDim.x;
-    const int cls = blockIdx.x & 7, idx_in_cls = blockIdx.x >> 3;
-    const int blk_per_cls = (nblk + 7 - cls) / 8;
-    const long long g_begin = total_groups * cls / 8 + (long long)idx_in_cls * A.group_step, g_end = total_groups * (cls + 1) / 8;
-    const long long g_stride = (long long)blk_per_cls * A.group_step;
-    if (g_begin >= g_end) return;                       // block-uniform
-
-    // unit sequence of a tile: stage L-1: M(0..NT-1) | stages L-2..0: Y0 Y1 M0 Y2 M1 .. Y(NT-1) M(NT-2) M(NT-1) | Wm1^T
-    const int n_units = NT + 2 * NT * (L - 1) + 1;
-    const f16x8* dma_src = A.units;
-    int dma_k = 0, dma_slot = 0, use_slot = 0;
-    auto dma_next = [&]() {
-        int kind = 0;                                    // 0: M, 1: Y, 2: Wm1^T
-        if (dma_k == n_units - 1) kind = 2;
-        else if (dma_k >= NT) {
-            const int r = (dma_k - NT) % (2 * NT);
-            kind = (r < 2 || ((r & 1) && r != 2 * NT - 1)) ? 1 : 0;
-        }
-        f16x8* dst = lds_units + dma_slot * SLOT_FR;
-        if (kind == 0) {
-            dma_pieces<P_M>(dma_src, dst, wave_u, lane);
-            dma_src += P_M * 64;
-        } else if (kind == 1) {
-            dma_pieces<P_Y>(dma_src, dst, wave_u, lane);
-            dma_src += P_Y * 64;
-        } else {
-            dma_pieces<P_W1>(dma_src, dst, wave_u, lane);
-            dma_src += P_W1 * 64;
-        }
-        if (++dma_k == n_units) {
-            dma_k = 0;
-            dma_src = A.units;
-        }
-        dma_slot = dma_slot == SLOTS - 1 ? 0 : dma_slot + 1;
-    };
-    // Every wave, at the start of every unit: its share of the unit's copy has landed.  The copy of unit k is requested two units earlier
-    // (three slots); vmcnt retires in order and the wait is written out: at most `younger` operations may stay in flight,
-    // a lower bound, known at the call site, on what the wave has issued since that request -- the copy instructions of unit k + 1
-    // (>= PWMIN), the prefetch of derivative rows behind an epilogue (12 loads; every wave issues it) -- so that the gradient stores and
-    // the prefetch stay in flight across the barrier, which orders LDS only.
-    constexpr int PWMIN = (P_Y < P_W1 ? P_Y : P_W1) / 4;
-    auto unit_begin = [&](int younger) -> const f16x8* {
-        if (younger >= 12) wait_vmcnt<12 + PWMIN>();
-        else wait_vmcnt<PWMIN>();
-        lds_only_barrier();
-        dma_next();
-        const f16x8* u = lds_units + use_slot * SLOT_FR;
-        use_slot = use_slot == SLOTS - 1 ? 0 : use_slot + 1;
-        return u;
-    };
-
-    for (int i = threadIdx.x; i < NT * 64; i += 256) lds_head[i] = A.head_t[i];
-    dma_next();
-    dma_next();
-    const float* winvY = A.winv;
-    const float* winvM = A.winv + L;
-    const float winvW1 = A.winv[2 * L], winv_head = A.winv[2 * L + 1];
-    const float S_go = A.scales[2 * (3 * L + 1)];
-
-    for (long long g = g_begin; g < g_end; g += g_stride) {
-        const int b = (int)(g / G);
-        const long long tile_in_image = (g - (long long)b * G) * 4 + wave;
-        const bool live = tile_in_image < a.tiles_per_image;                               // wave-uniform
-        const long long n = tile_in_image * 32 + j;
-        const bool valid = live && n < a.n_per_image;
-        const long long nn = n < a.n_per_image ? n : a.n_per_image - 1;
-        const size_t gpt = (size_t)b * a.n_per_image + nn;
-        const long long tile_T = (long long)b * a.tiles_per_image + (live ? tile_in_image : a.tiles_per_image - 1);
-        const size_t slab16 = (size_t)a.total_tiles * NT * 1024;
-        const size_t row16 = ((size_t)tile_T * NT * 32 + j) * 32;
-
-        // derivative rows: CD tiles ahead over the linear sequence (stage L-1 .. 0) x (tile 0 .. NT-1); past the end: the last tile again
-        f16x4 cosr[CD][3][4];
-        auto fetch_rows = [&](int lam, int t, int slot) {
-            const _Float16* src = A.cos16 + (size_t)(3 * lam) * slab16 + (((size_t)tile_T * NT + t) * 256 + lane) * 4;
-#pragma unroll
-            for (int s = 0; s < 3; ++s)
-#pragma unroll
-                for (int gq = 0; gq < 4; ++gq) cosr[slot][s][gq] = *reinterpret_cast<const f16x4*>(src + s * slab16 + gq * 256);
-        };
-        auto prefetch_after = [&](int lam, int t) {      // the rows of the tile CD positions behind (lam, t), into the slot (lam, t) just freed
-            int tn = t + CD, ln = lam;
-            if (tn >= NT) {
-                tn -= NT;
-                ln -= 1;
-            }
-            if (ln < 0) {
-                ln = 0;
-                tn = NT - 1;
-            }
-            fetch_rows(ln, tn, t % CD);
-        };
-#pragma unroll
-        for (int t = 0; t < CD; ++t) fetch_rows(L - 1, t, t);
-
-        // ---- head ----------------------------------------------------------------------------------------------------------------
-        f32x4 go = *reinterpret_cast<const f32x4*>(a.grad_out + gpt * 4);
-        if (!valid) go = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (a.flags & CNERF_F_SIGMOID_RGB) {
-            const f32x4 so = *reinterpret_cast<const f32x4*>(a.saved_out + gpt * 4);
-            go[0] = go[0] * (so[0] * (1.0f - so[0]));
-            go[1] = go[1] * (so[1] * (1.0f - so[1]));
-            go[2] = go[2] * (so[2] * (1.0f - so[2]));
-        }
-        float gs[4], gl[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            gs[i] = __builtin_amdgcn_fmed3f(go[i] * S_go, -60000.0f, 60000.0f);
-            gl[i] = gs[i] - (float)(_Float16)gs[i];
-        }
-        const float gomax = fmaxf(fmaxf(fabsf(go[0]), fabsf(go[1])), fmaxf(fabsf(go[2]), fabsf(go[3])));
-        if (DRY) {
-            float m4 = gomax;
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) m4 = fmaxf(m4, __shfl_xor(m4, d, WAVE));
-            if (lane == 0) atomicMax(A.gmax + 3 * L + 1, __float_as_uint(m4));
-        } else if (live && h == 0) {
-            *reinterpret_cast<u32x2_*>(A.go16 + ((size_t)tile_T * 32 + j) * 32) = u32x2_{pk_f16(gs[0], gs[1]), pk_f16(gs[2], gs[3])};
-        }
-
-        f32x16 gm[8];                                    // g_m in units of the current stage (true = gm winvM / T)
-#pragma unroll
-        for (int ot = 0; ot < 8; ++ot)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) gm[ot][r] = 0.0f;
-        u32x4 frag_in[KCH], frag_out[KCH];               // g_pre as the B operand: of the stage above (consumed), of this stage (produced)
-        float T_prev = 1.0f, gpremax_prev = 0.0f;
-
-        Epi st;
-        st.live = live;
-        st.slab = slab16;
-        // M(t): gm[ot] += sum over the 4 k-chunks (2 of g_fr, 2 of g_ph) of unit fragment (cc, ot) x operand cc; `ride(i)` runs behind MFMA i.
-        // RESCALE (the first M unit of a stage): each accumulator tile moves to the stage's units right before its first product --
-        // tile by tile, because accumulators live in the accumulation registers and vector instructions work on copies: all 128 values
-        // at once (a loop over gm at the stage boundary) spilled 300 registers
-        auto m_product = [&](const f16x8* unit, const u32x4* ffr, const u32x4* fph, auto rescale_tag, float rho, auto ride) {
-            constexpr bool RESCALE = decltype(rescale_tag)::value;
-            f16x8 ring[2] = {unit[lane], unit[64 + lane]};
-#pragma unroll
-            for (int i = 0; i < 32; ++i) {
-                const int cc = i >> 3, ot = i & 7;
-                const f16x8 aw = ring[i & 1];
-                if (i + 2 < 32) ring[i & 1] = unit[(i + 2) * 64 + lane];
-                if (RESCALE && i < 8) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) gm[ot][r] *= rho;
-                }
-                const u32x4 bq = cc < 2 ? ffr[cc] : fph[cc - 2];
-                gm[ot] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aw, __builtin_bit_cast(f16x8, bq), gm[ot], 0, 0, 0);
-                ride(i);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        };
-
-        for (int lam = L - 1; lam >= 0; --lam) {
-            // ---- scales of the stage -----------------------------------------------------------------------------------------
-            const float am = A.amax[((size_t)lam * a.total_tiles + tile_T) * 32 + j];
-            const bool first = lam == L - 1;
-            const float U = first ? winv_head / S_go : winvY[lam + 1] / T_prev;             // accumulator -> true g_y
-            const float bound = am * (first ? A.anorm[L] * gomax : A.anorm[lam + 1] * gpremax_prev);
-            const float T = pow2_to_2p14(bound);
-            st.UT = U * T;
-            st.USpre = U * A.scales[2 * (3 * lam)];
-            st.USfr = U * A.scales[2 * (3 * lam + 1)];
-            st.USph = U * A.scales[2 * (3 * lam + 2)];
-            st.mpre = st.mfr = st.mph = 0.0f;
-            st.gdst = A.g16 + (size_t)(3 * lam) * slab16 + row16 + 4 * h;
-            // g_m moves to this stage's units (both factors are powers of two): applied inside the stage's first M unit
-            const float rho = first ? 1.0f : (winvM[lam + 1] / winvM[lam]) * (T / T_prev);
-            u32x4 ffr[2][2], fph[2][2];                   // g_fr / g_ph operands of a tile (2 k-chunks each), by tile parity
-            f32x16 z;
-#pragma unroll
-            for (int t = 0; t <= NT; ++t) {
-                // ---- z_t -------------------------------------------------------------------------------------------------------
-                if (t < NT) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) z[r] = 0.0f;
-                    if (first) {
-                        const u32x4 bh = h == 0 ? u32x4{pk_f16(gs[0], gs[1]), pk_f16(gs[2], gs[3]), 0u, 0u} : u32x4{0u, 0u, 0u, 0u};
-                        const u32x4 bl = h == 0 ? u32x4{pk_f16(gl[0], gl[1]), pk_f16(gl[2], gl[3]), 0u, 0u} : u32x4{0u, 0u, 0u, 0u};
-                        const f16x8 aw = lds_head[t * 64 + lane];
-                        z = __builtin_amdgcn_mfma_f32_32x32x16_f16(aw, __builtin_bit_cast(f16x8, bl), z, 0, 0, 0);
-                        z = __builtin_amdgcn_mfma_f32_32x32x16_f16(aw, __builtin_bit_cast(f16x8, bh), z, 0, 0, 0);
-                    } else {
-                        // since the request of this unit's copy (two unit_begins ago) every wave has issued a prefetch: behind epilogue(t-1)
-                        // (t >= 1), behind the last epilogue of the stage above (t = 0)
-                        const f16x8* unit = unit_begin(12) + lane;
-                        f16x8 ring[2] = {unit[0], unit[64]};
-#pragma unroll
-                        for (int c = 0; c < KCH; ++c) {
-                            const f16x8 aw = ring[c & 1];
-                            if (c + 2 < KCH) ring[c & 1] = unit[(c + 2) * 64];
-                            z = __builtin_amdgcn_mfma_f32_32x32x16_f16(aw, __builtin_bit_cast(f16x8, frag_in[c]), z, 0, 0, 0);
-                        }
-                    }
-                }
-                // ---- epilogue(t), under the MFMAs of M(t-1) ------------------------------------------------------------------------
-                if (t == 0) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) epi_element<DRY>(z, cosr[0], 0, r, st, frag_out, ffr[0], fph[0]);
-                    prefetch_after(lam, 0);
-                } else {
-                    // since the request of this unit's copy (two unit_begins ago): t >= 2, or any t without Y units (stage L-1): the
-                    // prefetch behind epilogue(t-1); t = 1 behind Y units: the one behind epilogue(0)
-                    const f16x8* unit = unit_begin(12);
-                    auto ride = [&](int i) {
-                        if (t < NT && (i & 1)) epi_element<DRY>(z, cosr[t % CD], t, i >> 1, st, frag_out, ffr[t & 1], fph[t & 1]);
-                    };
-                    if (t == 1) m_product(unit, ffr[0], fph[0], RescaleYes{}, rho, ride);
-                    else m_product(unit, ffr[(t - 1) & 1], fph[(t - 1) & 1], RescaleNo{}, 1.0f, ride);
-                    if (t < NT) prefetch_after(lam, t);
-                }
-            }
-            // ---- end of the stage: maxima, operand bound of the next -------------------------------------------------------------------
-            const float mp = fmaxf(st.mpre, __shfl_xor(st.mpre, 32, WAVE));              // the two lane halves of a point
-            if (DRY) {
-                float v[3] = {mp * U, st.mfr * U, st.mph * U};
-#pragma unroll
-                for (int s = 0; s < 3; ++s) {
-                    float m4 = v[s];
-#pragma unroll
-                    for (int d = 32; d >= 1; d >>= 1) m4 = fmaxf(m4, __shfl_xor(m4, d, WAVE));
-                    if (lane == 0) atomicMax(A.gmax + 3 * lam + s, __float_as_uint(m4));
-                }
-            } else if (A.sat && live) {
-                const float worst = fmaxf(mp * st.USpre, fmaxf(st.mfr * st.USfr, st.mph * st.USph));
-                if (__any(worst > 65504.0f) && lane == 0) atomicAdd(A.sat, 1u);
-            }
-            gpremax_prev = mp * U;
-            T_prev = T;
-#pragma unroll
-            for (int c = 0; c < KCH; ++c) frag_in[c] = frag_out[c];
-        }
-
-        // ---- mapping network: g_mpre = g_m LeakyReLU'(m), g_feat = Wm1^T g_mpre --------------------------------------------------------
-        // (two passes over the 8 accumulator tiles, each tile by tile: the point's largest |g_mpre| must be known before the operand
-        // scale, and holding all 128 products in vector registers meanwhile is what spills)
-        const float Um = winvM[0] / T_prev;                                              // accumulator -> true g_m
-        const _Float16* mrow = A.m16 + ((size_t)tile_T * 8 * 32 + j) * 32 + 4 * h;
-        auto mpre_of = [&](int ot, int gq, f32x4& v) {
-            const f16x4 mq = *reinterpret_cast<const f16x4*>(mrow + ot * 1024 + 8 * gq);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = gm[ot][4 * gq + e] * Um * ((float)mq[e] > 0.0f ? 1.0f : 0.2f);
-        };
-        float mx = 0.0f;
-#pragma unroll
-        for (int ot = 0; ot < 8; ++ot) {
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                f32x4 v;
-                mpre_of(ot, gq, v);
-                mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, WAVE));
-        const float S_mp = A.scales[2 * (3 * L)];
-        if (DRY) {
-            float m4 = mx;
-#pragma unroll
-            for (int d = 16; d >= 1; d >>= 1) m4 = fmaxf(m4, __shfl_xor(m4, d, WAVE));
-            if (lane == 0) atomicMax(A.gmax + 3 * L, __float_as_uint(m4));
-        } else if (A.sat && live && __any(mx * S_mp > 65504.0f) && lane == 0) {
-            atomicAdd(A.sat, 1u);
-        }
-        const float Tm = pow2_to_2p14(mx);                                               // the point's own maximum: exact, no bound needed
-        u32x4 fm[16];
-        _Float16* gmp_dst = A.g16 + (size_t)(3 * L) * slab16 + ((size_t)tile_T * 8 * 32 + j) * 32 + 4 * h;
-#pragma unroll
-        for (int ot = 0; ot < 8; ++ot) {
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                f32x4 v;
-                mpre_of(ot, gq, v);
-                if (!DRY && live) {
-                    float q4[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) q4[e] = __builtin_amdgcn_fmed3f(v[e] * S_mp, -65504.0f, 65504.0f);
-                    *reinterpret_cast<u32x2_*>(gmp_dst + ot * 1024 + 8 * gq) = u32x2_{pk_f16(q4[0], q4[1]), pk_f16(q4[2], q4[3])};
-                }
-                // elements r = 4 gq + e of tile ot: chunk 2 ot + (r >> 3), dword (r & 7) >> 1
-                fm[2 * ot + (gq >> 1)][2 * (gq & 1)] = pk_f16(v[0] * Tm, v[1] * Tm);
-                fm[2 * ot + (gq >> 1)][2 * (gq & 1) + 1] = pk_f16(v[2] * Tm, v[3] * Tm);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        {
-            const f16x8* unit = unit_begin(0) + lane;
-            if (!DRY) {
-                f32x16 zf;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) zf[r] = 0.0f;
-#pragma unroll
-                for (int c = 0; c < 16; ++c) zf = __builtin_amdgcn_mfma_f32_32x32x16_f16(unit[c * 64], __builtin_bit_cast(f16x8, fm[c]), zf, 0, 0, 0);
-                const float U0 = winvW1 / Tm;
-                float px, py, pz;
-                tile_point(a, b, nn, valid, h, false, px, py, pz);
-                const int ch = lane & 31;
-                float* sg = s_g + wave * 32 * 33;
-                int* sb = s_base + wave * 32 * 8;
-                float* sw = s_w + wave * 32 * 8;
-                const int V = a.lvl_V[0], C = a.lvl_C[0];
-                Corner8 cr;
-                trilinear_corners(px, py, pz, a.half_voxel, V, cr);
-#pragma unroll
-                for (int gq = 0; gq < 4; ++gq)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) sg[j * 33 + 8 * gq + 4 * h + e] = zf[4 * gq + e] * U0;
-                if (h == 0) {
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        sb[j * 8 + k] = cr.base[k];
-                        sw[j * 8 + k] = valid ? cr.w[k] : 0.0f;
-                    }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                float* gv = a.lvl_grad[0] + (size_t)b * V * V * V * C;
-                // two points per wave instruction, 32 channels each: whole 128-byte corner lines per half-wave (as chain16_kernel)
-#pragma unroll 2
-                for (int pp = 0; pp < 16; ++pp) {
-                    const int p = 2 * pp + h;
-                    const float gval = sg[p * 33 + ch];
-                    const f32x4 w0 = *reinterpret_cast<const f32x4*>(sw + p * 8), w1 = *reinterpret_cast<const f32x4*>(sw + p * 8 + 4);
-                    const u32x4 b0 = *reinterpret_cast<const u32x4*>(sb + p * 8), b1 = *reinterpret_cast<const u32x4*>(sb + p * 8 + 4);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        atomicAdd(gv + (size_t)b0[k] * C + ch, gval * w0[k]);
-                        atomicAdd(gv + (size_t)b1[k] * C + ch, gval * w1[k]);
-                    }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-            }
-        }
-    }
-    wait_vmcnt<0>();
-    __syncthreads();                                    // drain the copy issued for a tile this block does not have
-}
-
-// =====================================================================================================================
-// The same chain as two kernels that fit their registers (the fused kernel above spills 195 dwords at H = 256 and turns them into
-// 64 GB of scratch traffic per launch):
-//   chain_pre_kernel   propagates g_y through W_l^T only -- operand g_y (cos f) -- and stores g_y itself, one TB16 slab per layer with its
-//                      own scale (DRY: sampled maxima); one derivative row to load, nothing resident but the two operand arrays;
-//   pw_gm_kernel       per layer and channel tile: g_y (fp16) x (cos, cos f, cos 15 pre) -> the three stored gradient slabs (scale = g_y's
-//                      x 2^-ceil(log2 max derivative): no overflow by construction) and the operands of the mapping products, g_m resident
-//                      in 8 accumulator tiles, then the tail (g_mpre, Wm1^T, volume scatter).  Operands carry per-LAYER scales here (the
-//                      stored g_y has no per-point one): a point whose gradient is 2^-20 of the largest contributes nothing to g_m -- or to
-//                      any sum over points.
-// =====================================================================================================================
+// chain_pre_kernel   propagates g_y through W_l^T only -- operand g_y (cos f) -- and stores g_y itself, one TB16 slab per layer with its own
+//                    scale (DRY instantiation: sampled maxima); one derivative row to load, nothing resident but the two operand arrays.
+// pw_gm_kernel       per layer and channel tile: g_y (fp16) x (cos, cos f, cos 15 pre) -> the three stored gradient slabs (scale = g_y's
+//                    x 2^-ceil(log2 largest derivative of the layer): no overflow by construction) and the operands of the mapping products
+//                    (M(l, t): the 4 k-chunks of tile t -- 2 of g_fr, 2 of g_ph -- against all 8 output tiles, one 32-KiB unit, so the operands of
+//                    a tile are consumed as soon as its epilogue has produced them), g_m resident in 8 accumulator tiles and moved to the next
+//                    layer's units tile by tile, then the tail (g_mpre, Wm1^T, volume scatter).  Operands carry per-LAYER scales here (the stored
+//                    g_y has no per-point one): a point whose gradient is 2^-20 of the largest contributes nothing to g_m -- or to any sum over
+//                    points.  The stored slabs see two fp16 roundings (g_y, then the product) instead of one.
 struct PreArgs {
     FieldArgs f;
     const f16x8* units;       // Y units: stages L-2 .. 0, NT units of KCH pieces each
     const f16x8* head_t;
-    const float* winv;        // as Args
-    const float* anorm;
+    const float* winv;        // 1 / s: [W_l^T: L (entry 0 unused) | Wm2 pair of layer l: L | Wm1^T | head^T]
+    const float* anorm;       // ||W_l||_1: L (entry 0 unused), then the head's
     const float* scales;      // {S, 1 / S}: index 3 L + 1: go; 3 L + 2 + l: g_y of layer l
     const _Float16* cos16;    // 3 L COS16 slabs; this kernel reads cos f (slab 3 l + 1)
     const float* amax;
@@ -857,7 +425,7 @@ __global__ __launch_bounds__(256) void pw_gm_kernel(GmArgs A) {
                 if (t < NT) prefetch_after(l, t);
             }
         }
-        // ---- mapping network tail: as the fused kernel's ---------------------------------------------------------------------------
+        // ---- mapping network: g_mpre = g_m LeakyReLU'(m) (its operand scale from the point's exact maximum), g_feat = Wm1^T g_mpre ---------------
         const float Um = 1.0f / unit_prev;
         const _Float16* mrow = A.m16 + ((size_t)tile_T * 8 * 32 + j) * 32 + 4 * h;
         auto mpre_of = [&](int ot, int gq, f32x4& v) {
@@ -991,18 +559,8 @@ __device__ __forceinline__ float pow2_weight_scale(uint32_t wmax_bits) {
     return ldexpf(1.0f, e - 1 > 100 ? 100 : e - 1);
 }
 
-// first piece of a unit inside one stage's part of the stream (pieces of 1 KiB; stage L-1 holds only its M units)
-__host__ __device__ inline long long stage_piece(int NT, bool first_stage, bool is_m, int t, int split = 0) {
-    const int KCH = 2 * NT;
-    if (split) return (long long)t * (is_m ? 32 : KCH);       // the two-kernel chain: Y units and M units in streams of their own
-    if (first_stage) return (long long)t * 32;
-    if (!is_m) return t < 2 ? (long long)t * KCH : 2LL * KCH + (long long)(t - 2) * (32 + KCH) + 32;
-    return t <= NT - 2 ? 2LL * KCH + (long long)t * (32 + KCH) : 2LL * KCH + (long long)(NT - 2) * (32 + KCH) + 32;
-}
-
 // Y(l, t) for all t: rows [32 t, 32 t + 32) of W_l^T (W_l row-major (H, H)), KCH k-chunks
-__global__ void pack_y_kernel(const float* __restrict__ w, int H, int NT, const uint32_t* wmax_slot, float* winv_slot, _Float16* __restrict__ stage_dst,
-                              int split) {
+__global__ void pack_y_kernel(const float* __restrict__ w, int H, int NT, const uint32_t* wmax_slot, float* winv_slot, _Float16* __restrict__ stage_dst) {
     const float s = pow2_weight_scale(*wmax_slot);
     if (blockIdx.x == 0 && threadIdx.x == 0) *winv_slot = 1.0f / s;
     const int KCH = 2 * NT;
@@ -1011,14 +569,14 @@ __global__ void pack_y_kernel(const float* __restrict__ w, int H, int NT, const 
         const int jj = (int)(idx & 7), lane = (int)((idx >> 3) & 63);
         const int c = (int)((idx >> 9) % KCH), t = (int)((idx >> 9) / KCH);
         const int r = 32 * t + (lane & 31), k = 16 * c + 8 * (jj >> 2) + 4 * (lane >> 5) + (jj & 3);
-        stage_dst[stage_piece(NT, false, false, t, split) * 512 + ((size_t)c * 64 + lane) * 8 + jj] = (_Float16)(w[(size_t)k * H + r] * s);
+        stage_dst[(size_t)t * KCH * 512 + ((size_t)c * 64 + lane) * 8 + jj] = (_Float16)(w[(size_t)k * H + r] * s);
     }
 }
 
 // M(l, t) for all t: fragment (cc, ot), cc = 0, 1: freq rows, 2, 3: phase rows of the layer; k = channel 32 t + 16 (cc & 1) + ..; output row
 // 32 ot + i of the 256 inputs of the mapping network's second Linear (Wm2 row-major (2 L H, 256))
-__global__ void pack_m_kernel(const float* __restrict__ wm2, int H, int NT, int row_f, int row_p, int first_stage, const uint32_t* wmax_slot,
-                              float* winv_slot, _Float16* __restrict__ stage_dst, int split) {
+__global__ void pack_m_kernel(const float* __restrict__ wm2, int H, int NT, int row_f, int row_p, const uint32_t* wmax_slot, float* winv_slot,
+                              _Float16* __restrict__ stage_dst) {
     const float s = pow2_weight_scale(*wmax_slot);
     if (blockIdx.x == 0 && threadIdx.x == 0) *winv_slot = 1.0f / s;
     const long long total = (long long)NT * 32 * 512;
@@ -1028,24 +586,8 @@ __global__ void pack_m_kernel(const float* __restrict__ wm2, int H, int NT, int 
         const int cc = f >> 3, ot = f & 7;
         const int chan = 32 * t + 16 * (cc & 1) + 8 * (jj >> 2) + 4 * (lane >> 5) + (jj & 3);
         const int row = (cc < 2 ? row_f : row_p) + chan;
-        stage_dst[stage_piece(NT, first_stage != 0, true, t, split) * 512 + ((size_t)f * 64 + lane) * 8 + jj] = (_Float16)(wm2[(size_t)row * 256 + 32 * ot + (lane & 31)] * s);
+        stage_dst[(size_t)t * 32 * 512 + ((size_t)f * 64 + lane) * 8 + jj] = (_Float16)(wm2[(size_t)row * 256 + 32 * ot + (lane & 31)] * s);
     }
-}
-
-template <int NT, bool DRY>
-static hipError_t launch_nt(const Args& A, hipStream_t stream) {
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
-    const size_t lds_bytes = (size_t)3 * 32 * 1024 + (size_t)NT * 1024 + (size_t)4 * 32 * 33 * 4 + (size_t)2 * 4 * 32 * 8 * 4;
-    if (hipError_t e = hipFuncSetAttribute((const void*)chain_pw16_kernel<NT, DRY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)) return e;
-    const FieldArgs& f = A.f;
-    const long long want = (f.total_tiles / f.tiles_per_image) * ((f.tiles_per_image + 3) / 4);
-    int blocks = (int)(want < cus ? want : cus);
-    if (blocks < 8) blocks = 8;
-    blocks = (blocks + 7) / 8 * 8;
-    hipLaunchKernelGGL((chain_pw16_kernel<NT, DRY>), dim3(blocks), dim3(256), lds_bytes, stream, A);
-    return hipGetLastError();
 }
 
 template <int NT, bool DRY>
@@ -1133,43 +675,13 @@ hipError_t launch_pw_split_scales(const uint32_t* amaxg_bits, int L, float* scal
     return L <= 64 ? hipGetLastError() : hipErrorInvalidValue;
 }
 
-hipError_t launch_chain_pw16(const FieldArgs& f, int H, const PwChainBuffers& c, int dry, int group_step, hipStream_t stream) {
-    if (f.n_in != 1 || f.in_level[0] < 0 || f.L < 1 || 3 * f.L + 2 > 64) return hipErrorInvalidValue;
-    pwchain::Args A;
-    A.f = f;
-    A.units = (const f16x8*)c.units;
-    A.head_t = (const f16x8*)c.head_t;
-    A.winv = c.winv;
-    A.anorm = c.anorm;
-    A.scales = c.scales;
-    A.cos16 = (const _Float16*)c.cos16;
-    A.amax = c.amax;
-    A.m16 = (const _Float16*)c.m16;
-    A.g16 = (_Float16*)c.g16;
-    A.go16 = (_Float16*)c.go16;
-    A.gmax = c.gmax;
-    A.sat = c.sat;
-    A.group_step = group_step < 1 ? 1 : group_step;
-    switch (H / 32) {
-        case 2: return dry ? pwchain::launch_nt<2, true>(A, stream) : pwchain::launch_nt<2, false>(A, stream);
-        case 4: return dry ? pwchain::launch_nt<4, true>(A, stream) : pwchain::launch_nt<4, false>(A, stream);
-        case 8: return dry ? pwchain::launch_nt<8, true>(A, stream) : pwchain::launch_nt<8, false>(A, stream);
-        default: return hipErrorInvalidValue;
-    }
-}
+// Y units (stages L-2 .. 0, NT x KCH pieces each) | M units (layers 0 .. L-1, NT x 32 pieces each) + Wm1^T (16 pieces)
+size_t pw_chain_y_bytes(int L, int H) { return (size_t)(L > 1 ? L - 1 : 0) * (H / 32) * (2 * (H / 32)) * 1024; }
+size_t pw_chain_m_bytes(int L, int H) { return ((size_t)L * (H / 32) * 32 + 16) * 1024; }
 
-// bytes of the unit stream: stage L-1: NT M units; stages L-2 .. 0: NT (Y + M); Wm1^T
-size_t pw_chain_units_bytes(int L, int H) {
-    const size_t NT = H / 32, KCH = 2 * NT;
-    return (NT * 32 + (size_t)(L - 1) * NT * (32 + KCH) + 16) * 1024;
-}
-// the two-kernel chain: Y units (stages L-2 .. 0, NT x KCH pieces each) | M units (layers 0 .. L-1, NT x 32 pieces each) + Wm1^T (16 pieces)
-size_t pw_chain_split_y_bytes(int L, int H) { return (size_t)(L > 1 ? L - 1 : 0) * (H / 32) * (2 * (H / 32)) * 1024; }
-size_t pw_chain_split_m_bytes(int L, int H) { return ((size_t)L * (H / 32) * 32 + 16) * 1024; }
-
-// the whole stream; winv: [W_l^T: L (0 unused) | Wm2 pair of layer l: L | Wm1^T | head^T], anorm: [||W_l||_1: L (0 unused) | head], wmax: 2 L + 2 scratch words
-hipError_t launch_pack_pw_chain(const cnerf_field_params* p, int L, int H, void* units, void* head_t, float* winv, float* anorm, uint32_t* wmax,
-                                hipStream_t stream, void* units_y, void* units_m) {
+// both streams; winv: [W_l^T: L (0 unused) | Wm2 pair of layer l: L | Wm1^T | head^T], anorm: [||W_l||_1: L (0 unused) | head], wmax: 2 L + 2 scratch words
+hipError_t launch_pack_pw_chain(const cnerf_field_params* p, int L, int H, void* units_y, void* units_m, void* head_t, float* winv, float* anorm,
+                                uint32_t* wmax, hipStream_t stream) {
     const int NT = H / 32, KCH = 2 * NT;
     if (hipError_t e = hipMemsetAsync(wmax, 0, (size_t)(2 * L + 2) * sizeof(uint32_t), stream)) return e;
     if (hipError_t e = hipMemsetAsync(winv, 0, (size_t)(2 * L + 2) * sizeof(float), stream)) return e;
@@ -1181,32 +693,19 @@ hipError_t launch_pack_pw_chain(const cnerf_field_params* p, int L, int H, void*
         if (hipError_t e = launch_absmax_bits(p->map_w2 + (size_t)l * H * 256, (long long)H * 256, wmax + L + l, stream)) return e;
         if (hipError_t e = launch_absmax_bits(p->map_w2 + (LH + (size_t)l * H) * 256, (long long)H * 256, wmax + L + l, stream)) return e;
     }
-    _Float16* dst = (_Float16*)units;
-    for (int lam = L - 1; lam >= 0; --lam) {
-        const bool first = lam == L - 1;
-        if (!first) {
-            hipLaunchKernelGGL(pwchain::pack_y_kernel, dim3(64), dim3(256), 0, stream, p->w[lam + 1], H, NT, (const uint32_t*)(wmax + lam + 1), winv + lam + 1, dst, 0);
-        }
-        hipLaunchKernelGGL(pwchain::pack_m_kernel, dim3(128), dim3(256), 0, stream, p->map_w2, H, NT, lam * H, (int)(LH + (size_t)lam * H), first ? 1 : 0,
-                           (const uint32_t*)(wmax + L + lam), winv + L + lam, dst, 0);
-        dst += (size_t)NT * (32 + (first ? 0 : KCH)) * 512;
+    _Float16* dy = (_Float16*)units_y;
+    for (int lam = L - 2; lam >= 0; --lam) {             // consumption order of chain_pre_kernel: the stage that produces g_y of layer lam multiplies by W_{lam+1}^T
+        hipLaunchKernelGGL(pwchain::pack_y_kernel, dim3(64), dim3(256), 0, stream, p->w[lam + 1], H, NT, (const uint32_t*)(wmax + lam + 1), winv + lam + 1, dy);
+        dy += (size_t)NT * KCH * 512;
+    }
+    _Float16* dm = (_Float16*)units_m;
+    for (int l = 0; l < L; ++l) {
+        hipLaunchKernelGGL(pwchain::pack_m_kernel, dim3(128), dim3(256), 0, stream, p->map_w2, H, NT, l * H, (int)(LH + (size_t)l * H),
+                           (const uint32_t*)(wmax + L + l), winv + L + l, dm);
+        dm += (size_t)NT * 32 * 512;
     }
     // Wm1^T: one output tile (the 32 feature channels), K = 256; Wm1 row-major (256, 32)
-    if (hipError_t e = launch_pack_t16(p->map_w1, 256, 32, 32, 1, dst, winv + 2 * L, wmax + 2 * L, stream)) return e;
-    if (units_y && units_m) {            // the two-kernel chain's streams (same scales)
-        _Float16* dy = (_Float16*)units_y;
-        for (int lam = L - 2; lam >= 0; --lam) {
-            hipLaunchKernelGGL(pwchain::pack_y_kernel, dim3(64), dim3(256), 0, stream, p->w[lam + 1], H, NT, (const uint32_t*)(wmax + lam + 1), winv + lam + 1, dy, 1);
-            dy += (size_t)NT * KCH * 512;
-        }
-        _Float16* dm = (_Float16*)units_m;
-        for (int l = 0; l < L; ++l) {
-            hipLaunchKernelGGL(pwchain::pack_m_kernel, dim3(128), dim3(256), 0, stream, p->map_w2, H, NT, l * H, (int)(LH + (size_t)l * H), 0,
-                               (const uint32_t*)(wmax + L + l), winv + L + l, dm, 1);
-            dm += (size_t)NT * 32 * 512;
-        }
-        if (hipError_t e = launch_pack_t16(p->map_w1, 256, 32, 32, 1, dm, winv + 2 * L, wmax + 2 * L, stream)) return e;
-    }
+    if (hipError_t e = launch_pack_t16(p->map_w1, 256, 32, 32, 1, dm, winv + 2 * L, wmax + 2 * L, stream)) return e;
     if (hipError_t e = launch_pack_head_t16(p->w_final, H, head_t, winv + 2 * L + 1, wmax + 2 * L + 1, stream)) return e;
     for (int l = 1; l < L; ++l)
         if (hipError_t e = launch_col_abs_sum_max(p->w[l], H, H, anorm + l, stream)) return e;

@@ -3,7 +3,6 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
-#include <stdlib.h>
 #include <string.h>
 
 #include "cnerf_kernels.hpp"
@@ -796,16 +795,15 @@ int chain16_layout(const cnerf_cfg* c, Chain16Layout& l) {
 }  // namespace
 
 namespace {
-// per-point FiLM family (chain_pw16.hip): [unit stream][head^T: NT fragments x 64 lanes][winv: 2 L + 2][anorm: L + 1][max|W| scratch: 2 L + 2]
+// per-point FiLM family (chain_pw16.hip): [Y units][M units + Wm1^T][head^T: NT fragments x 64 lanes][winv: 2 L + 2][anorm: L + 1][max|W| scratch: 2 L + 2]
 struct PwChainLayout {
-    size_t y_off, m_off, head_off, winv_off, anorm_off, wmax_off, total;
+    size_t m_off, head_off, winv_off, anorm_off, wmax_off, total;
 };
 PwChainLayout pw_chain_layout(const cnerf_cfg* c) {
     PwChainLayout l;
     const size_t NT = c->H / 32, L = c->L;
-    l.y_off = align256(pw_chain_units_bytes(c->L, c->H));           // (fused stream first, then the two-kernel chain's Y and M streams)
-    l.m_off = l.y_off + align256(pw_chain_split_y_bytes(c->L, c->H));
-    l.head_off = l.m_off + align256(pw_chain_split_m_bytes(c->L, c->H));
+    l.m_off = align256(pw_chain_y_bytes(c->L, c->H));
+    l.head_off = l.m_off + align256(pw_chain_m_bytes(c->L, c->H));
     l.winv_off = l.head_off + align256(NT * 1024);
     l.anorm_off = l.winv_off + align256((2 * L + 2) * sizeof(float));
     l.wmax_off = l.anorm_off + align256((L + 1) * sizeof(float));
@@ -837,8 +835,8 @@ int cnerf_pack_field_chain16(const cnerf_cfg* cfg, const cnerf_field_params* p, 
         if (cfg->C != 32 || cfg->n_levels > 1) return fail(CNERF_EINVAL, "per-point FiLM: a single 32-channel feature volume is supported");
         const PwChainLayout l = pw_chain_layout(cfg);
         char* base = (char*)packed16;
-        if (hipError_t e = launch_pack_pw_chain(p, cfg->L, cfg->H, base, base + l.head_off, (float*)(base + l.winv_off), (float*)(base + l.anorm_off),
-                                                (uint32_t*)(base + l.wmax_off), (hipStream_t)stream_, base + l.y_off, base + l.m_off))
+        if (hipError_t e = launch_pack_pw_chain(p, cfg->L, cfg->H, base, base + l.m_off, base + l.head_off, (float*)(base + l.winv_off),
+                                                (float*)(base + l.anorm_off), (uint32_t*)(base + l.wmax_off), (hipStream_t)stream_))
             return hip_fail(e, "pack_pw_chain");
         return CNERF_OK;
     }
@@ -1094,8 +1092,8 @@ int cnerf_render_backward(const cnerf_cfg* cfg, int32_t bprec, int32_t cnt_max, 
         return rc;
 
     if (cfg->layer_kind[0] == CNERF_LAYER_PFILM) {
-        // ---- per-point FiLM family, half-precision backward: storing forward (field_pw16.hip), dry run -> scales, chain (chain_pw16.hip),
-        // one weight_grad16 reduction per matrix: dW_l = g_pre_l^T y_{l-1}, dWm2 rows = (g_fr_l | g_ph_l)^T m, dWm1 = g_mpre^T feat, head
+        // ---- per-point FiLM family, half-precision backward: storing forward (field_pw16.hip), the two chain kernels with their dry runs
+        // (chain_pw16.hip), one weight_grad16 reduction per matrix: dW_l = g_pre_l^T y_{l-1}, dWm2 rows = (g_fr_l | g_ph_l)^T m, dWm1 = g_mpre^T feat, head
         const int Lc = cfg->L, n_slots = 3 * Lc + 2;
         if (!P->map_w1 || !P->map_w2 || !P->w_final) return fail(CNERF_EINVAL, "render_backward: mapping network / head parameters are NULL");
         if (!G->map_w1 || !G->map_b1 || !G->map_w2 || !G->map_b2 || !G->w_final || !G->b_final)
@@ -1158,35 +1156,26 @@ int cnerf_render_backward(const cnerf_cfg* cfg, int32_t bprec, int32_t cnt_max, 
                     if (hipError_t e = launch_fill(scales + 2 * m, 1.0f, 2, stream)) return hip_fail(e, "fill");
                 const size_t slabH = (size_t)T * NT * 2048;            // bytes per (tiles, NT, 32, 32) slab
                 float* lay = scales + 2 * (4 * Lc + 2);
-                PwChainBuffers cb{base16, base16 + cl.head_off, (const float*)(base16 + cl.winv_off), (const float*)(base16 + cl.anorm_off), scales, a_c,
-                                  a_amax, a_h + (size_t)Lc * slabH, a_g, a_go, gmax, nullptr,
-                                  base16 + cl.y_off, base16 + cl.m_off, ws + L.a_gy, lay};
+                PwChainBuffers cb{base16, base16 + cl.m_off, base16 + cl.head_off, (const float*)(base16 + cl.winv_off), (const float*)(base16 + cl.anorm_off),
+                                  scales, lay, a_c, a_amax, a_h + (size_t)Lc * slabH, ws + L.a_gy, a_g, a_go, gmax, nullptr};
                 const long long groups = (long long)cnt * ((tpi + 3) / 4);
                 long long step = groups / 1024;                       // dry-run sampling: at least 1024 tile groups (131 k points), every 32nd at most
                 step = step < 1 ? 1 : (step > 32 ? 32 : step);
-                static const bool fused = getenv("CNERF_PW_FUSED_CHAIN") != nullptr;      // (A/B switch of the round: the one-kernel chain)
-                if (fused) {
-                    if (hipError_t e = launch_chain_pw16(fa, H, cb, 1, (int)step, stream)) return hip_fail(e, "chain_pw16 (dry run)");
-                    if (hipError_t e = launch_pow2_scales(gmax, n_slots - 1, scales, stream)) return hip_fail(e, "pow2_scales");
-                    cb.sat = saturated;
-                    if (hipError_t e = launch_chain_pw16(fa, H, cb, 0, 1, stream)) return hip_fail(e, "chain_pw16");
-                } else {
-                    // two kernels: g_y through the layer matrices (dry run -> its scales), then the mapping products and the stored slabs
-                    for (int m = 0; m < Lc; ++m)
-                        if (hipError_t e = launch_fill(scales + 2 * (3 * Lc + 2 + m), 1.0f, 2, stream)) return hip_fail(e, "fill");
-                    if (hipError_t e = launch_chain_pre(fa, H, cb, 1, (int)step, stream)) return hip_fail(e, "chain_pre (dry run)");
-                    if (hipError_t e = launch_pow2_scales(gmax + 3 * Lc + 2, Lc, scales + 2 * (3 * Lc + 2), stream)) return hip_fail(e, "pow2_scales");
-                    for (int m = 0; m < Lc; ++m)      // the largest stored derivative of each layer over the chunk's points
-                        if (hipError_t e = launch_absmax_bits(a_amax + (size_t)m * T * 32, T * 32, gmax + 4 * Lc + 2 + m, stream)) return hip_fail(e, "absmax");
-                    if (hipError_t e = launch_pw_split_scales(gmax + 4 * Lc + 2, Lc, scales, lay, stream)) return hip_fail(e, "split_scales");
-                    cb.sat = saturated;
-                    if (hipError_t e = launch_chain_pre(fa, H, cb, 0, 1, stream)) return hip_fail(e, "chain_pre");
-                    cb.sat = nullptr;
-                    if (hipError_t e = launch_pw_gm(fa, H, cb, 1, (int)step, stream)) return hip_fail(e, "pw_gm (dry run)");
-                    if (hipError_t e = launch_pow2_scales(gmax + 3 * Lc, 1, scales + 2 * (3 * Lc), stream)) return hip_fail(e, "pow2_scales");
-                    cb.sat = saturated;
-                    if (hipError_t e = launch_pw_gm(fa, H, cb, 0, 1, stream)) return hip_fail(e, "pw_gm");
-                }
+                // g_y through the layer matrices (dry run -> its scales), then the stored slabs and the mapping products (dry run -> g_mpre's scale)
+                for (int m = 0; m < Lc; ++m)
+                    if (hipError_t e = launch_fill(scales + 2 * (3 * Lc + 2 + m), 1.0f, 2, stream)) return hip_fail(e, "fill");
+                if (hipError_t e = launch_chain_pre(fa, H, cb, 1, (int)step, stream)) return hip_fail(e, "chain_pre (dry run)");
+                if (hipError_t e = launch_pow2_scales(gmax + 3 * Lc + 2, Lc, scales + 2 * (3 * Lc + 2), stream)) return hip_fail(e, "pow2_scales");
+                for (int m = 0; m < Lc; ++m)      // the largest stored derivative of each layer over the chunk's points
+                    if (hipError_t e = launch_absmax_bits(a_amax + (size_t)m * T * 32, T * 32, gmax + 4 * Lc + 2 + m, stream)) return hip_fail(e, "absmax");
+                if (hipError_t e = launch_pw_split_scales(gmax + 4 * Lc + 2, Lc, scales, lay, stream)) return hip_fail(e, "split_scales");
+                cb.sat = saturated;
+                if (hipError_t e = launch_chain_pre(fa, H, cb, 0, 1, stream)) return hip_fail(e, "chain_pre");
+                cb.sat = nullptr;
+                if (hipError_t e = launch_pw_gm(fa, H, cb, 1, (int)step, stream)) return hip_fail(e, "pw_gm (dry run)");
+                if (hipError_t e = launch_pow2_scales(gmax + 3 * Lc, 1, scales + 2 * (3 * Lc), stream)) return hip_fail(e, "pow2_scales");
+                cb.sat = saturated;
+                if (hipError_t e = launch_pw_gm(fa, H, cb, 0, 1, stream)) return hip_fail(e, "pw_gm");
                 // one reduction: G (n_rows of slab `slot`) against X (x_ct channel tiles), take k_real columns from column k0 on
                 auto reduce = [&](const void* Gs, int g_ct, int n_rows, int slot, const void* X, int x_ct, int k0, int k_real, float* dW, float* db) -> int {
                     if (hipError_t e = hipMemsetAsync(dwarg, 0, (size_t)cnt * n_rows * 32 * x_ct * sizeof(float), stream)) return hip_fail(e, "memset");

@@ -202,34 +202,30 @@ hipError_t launch_chain16(const FieldArgs& f, int H, const void* units, const vo
 hipError_t launch_weight_grad16(int cnt, long long tiles_per_image, int n_rows, int g_ct, int x_ct, const void* G, const void* X, float* dW,
                                 float* colsum, const float* inv_scale, hipStream_t stream);
 
-// chain_pw16.hip: half-precision gradient chain of the per-point FiLM family
+// chain_pw16.hip: half-precision gradient chain of the per-point FiLM family (chain_pre_kernel + pw_gm_kernel)
 struct PwChainBuffers {
-    const void* units;        // transposed weight units (launch_pack_pw_chain)
+    const void* units_y;      // Y units: W_l^T, stages L-2 .. 0 (launch_pack_pw_chain)
+    const void* units_m;      // M units: the Wm2 pair of every layer by channel tile, then Wm1^T
     const void* head_t;
     const float* winv;        // [W_l^T: L (0 unused) | Wm2 pair of layer l: L | Wm1^T | head^T]
     const float* anorm;       // [||W_l||_1: L (0 unused) | head]
-    const float* scales;      // {S, 1 / S} x (3 L + 2): per layer (g_pre, g_fr, g_ph), g_mpre, go
+    const float* scales;      // {S, 1 / S} x (4 L + 2): per layer (g_pre, g_fr, g_ph), g_mpre, go, then g_y per layer
+    const float* lay;         // per layer {r_l, To_l} (launch_pw_split_scales)
     const void* cos16;        // 3 L COS16 slabs of the storing forward
     const float* amax;        // (L, tiles * 32)
     const void* m16;          // TB16 (tiles, 8, 32, 32)
+    void* gy16;               // TB16: L slabs (tiles, NT, 32, 32) of g_y
     void* g16;                // TB16: 3 L slabs (tiles, NT, 32, 32) then g_mpre (tiles, 8, 32, 32)
     void* go16;
-    unsigned int* gmax;       // dry run: 3 L + 2 maxima (two-kernel chain: + L maxima of g_y)
+    unsigned int* gmax;       // dry runs: 3 L: g_mpre, 3 L + 1: go, 3 L + 2 + l: g_y of layer l
     unsigned int* sat;
-    // the two-kernel chain (chain_pre_kernel + pw_gm_kernel)
-    const void* units_y;      // Y units
-    const void* units_m;      // M units + Wm1^T
-    void* gy16;               // TB16: L slabs (tiles, NT, 32, 32) of g_y
-    const float* lay;         // per layer {r_l, To_l}
 };
 hipError_t launch_chain_pre(const FieldArgs& f, int H, const PwChainBuffers& c, int dry, int group_step, hipStream_t stream);
 hipError_t launch_pw_gm(const FieldArgs& f, int H, const PwChainBuffers& c, int dry, int group_step, hipStream_t stream);
 hipError_t launch_pw_split_scales(const uint32_t* amaxg_bits, int L, float* scales, float* lay, hipStream_t stream);
-size_t pw_chain_split_y_bytes(int L, int H);
-size_t pw_chain_split_m_bytes(int L, int H);
-hipError_t launch_chain_pw16(const FieldArgs& f, int H, const PwChainBuffers& c, int dry, int group_step, hipStream_t stream);
-size_t pw_chain_units_bytes(int L, int H);
-hipError_t launch_pack_pw_chain(const cnerf_field_params* p, int L, int H, void* units, void* head_t, float* winv, float* anorm, uint32_t* wmax,
-                                hipStream_t stream, void* units_y = nullptr, void* units_m = nullptr);
+size_t pw_chain_y_bytes(int L, int H);
+size_t pw_chain_m_bytes(int L, int H);
+hipError_t launch_pack_pw_chain(const cnerf_field_params* p, int L, int H, void* units_y, void* units_m, void* head_t, float* winv, float* anorm,
+                                uint32_t* wmax, hipStream_t stream);
 
 }  // namespace cnerf
