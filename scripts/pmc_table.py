@@ -6,8 +6,8 @@ active shares of SQ_WAVE_CYCLES; HBM bytes = 2 * FETCH_SIZE + WRITE_SIZE (KB, gf
 import collections, csv, glob, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNELS = {"fwd32": ["void cnerf::field_tile_kernel"], "fwd16": ["void cnerf::h3::field_h3_kernel"],
-           "pfilm": ["void cnerf::h3::pw::field_pw16_kernel<8, false", "void cnerf::h3::pw::field_pw16_kernel<8, true", "void cnerf::h3::pw::pw_deriv_kernel<8", "void cnerf::pwchain::chain_pw16_kernel<8, false",
-                     "void cnerf::pwchain::chain_pw16_kernel<8, true", "void cnerf::weight_grad16_kernel<8, 8"],
+           "pfilm": ["void cnerf::h3::pw::field_pw16_kernel<8, false", "void cnerf::h3::pw::field_pw16_kernel<8, true", "void cnerf::h3::pw::pw_deriv_kernel<8", "void cnerf::pwchain::chain_pre_kernel<8, false",
+                     "void cnerf::pwchain::pw_gm_kernel<8, false", "void cnerf::weight_grad16_kernel<8, 8"],
            "bwd16": ["void cnerf::h3::field_h3_kernel<8, 2", "void cnerf::chain16_kernel<8, false", "void cnerf::weight_grad16_kernel<8, 8", "void cnerf::weight_grad16_kernel<1, 8", "cnerf::gather_kernel"]}
 vals = collections.defaultdict(lambda: collections.defaultdict(list))      # (workload, kernel) -> counter -> values
 durs = collections.defaultdict(list)
