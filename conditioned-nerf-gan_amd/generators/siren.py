@@ -178,7 +178,7 @@ class TALLSIREN(FieldNetwork):
     POINT from a mapping MLP of the looked-up feature (z is the bare feature volume, z_dim = its channel count).
     Parameters, names and initialisation mirror the reference so its checkpoints load.  Forward: field_pw_kernel (fp32) or
     field_pw16_kernel (fp16x3 / fp16); backward: storing forward + field_pw_backward_kernel + library GEMMs (fp32,
-    ops._pfilm_backward) or chain_pw16_kernel + weight_grad16 behind cnerf_render_backward (backward_precision "fp16")."""
+    ops._pfilm_backward) or chain_pre_kernel + pw_gm_kernel + weight_grad16 behind cnerf_render_backward (backward_precision "fp16")."""
     variant = "TALLSIREN"
     spec = FieldSpec(("pfilm",) * 8, 25, False, False, False, "xyz")
 

@@ -1020,7 +1020,7 @@ def test_backward_per_point_film_vs_oracle_autograd(dev, shape):
     """The same for TALLSIREN (per-point FiLM, siren.py:232-331): storing forward + gradient chain kernels, weight-gradient
     reductions and the mapping network's GEMMs against autograd through the CPU oracle, at all three widths and ragged tiles --
     the exact fp32 path (field_pw_backward_kernel + library GEMMs) and the half-precision one (field_pw16 storing forward,
-    chain_pw16_kernel, weight_grad16 behind cnerf_render_backward)."""
+    pw_deriv_kernel, chain_pre_kernel, pw_gm_kernel, weight_grad16 behind cnerf_render_backward)."""
     _ragged_backward_case(dev, shape, "TALLSIREN", ("fp32", "fp16"))
 
 
