@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void chain_pre_kernel(PreArgs A) {
     for (int i = threadIdx.x; i < NT * 64; i += 256) lds_head[i] = A.head_t[i];
     dma_next();
     dma_next();
-    if (n_units == 0) __syncthreads();                  // (the head fragments: otherwise published by the first unit's barrier)
+    __syncthreads();                                    // the head fragments are plain LDS stores: published here, once
     const float winv_head = A.winv[2 * L + 1];
     const float S_go = A.scales[2 * (3 * L + 1)];
 

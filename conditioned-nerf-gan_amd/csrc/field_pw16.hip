@@ -268,6 +268,7 @@ __global__ __launch_bounds__(256) void field_pw16_kernel(FieldArgs a) {
     for (int i = threadIdx.x; i < a.bias_floats; i += 256) lds_c[i] = a.bias[i];
     dma_next();
     dma_next();
+    __syncthreads();             // the constants are plain LDS stores: published here, once (the unit barriers order LDS-DMA data only)
 
     for (long long g = g_begin; g < g_end; g += blk_per_cls) {
         const TilePoint tp = tile_of_group(a, g, G, wave, j);
@@ -544,6 +545,7 @@ __global__ __launch_bounds__(256) void pw_deriv_kernel(FieldArgs a) {
     for (int i = threadIdx.x; i < a.bias_floats; i += 256) lds_c[i] = a.bias[i];
     dma_next();
     dma_next();
+    __syncthreads();             // the constants are plain LDS stores: published here, once (the unit barriers order LDS-DMA data only)
 
     for (long long g = g_begin; g < g_end; g += blk_per_cls) {
         const int b = (int)(g / G);
