@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcnerf_hip.so")
-SOURCES = ["cnerf_abi.hip", "field_kernel.hip", "field_h3.hip", "field_pw16.hip", "ray_kernels.hip", "grad_kernels.hip", "bwd16.hip", "chain_pw16.hip"]
+SOURCES = ["cnerf_abi.hip", "field_kernel.hip", "field_h3.hip", "field_pw16.hip", "ray_kernels.hip", "grad_kernels.hip", "bwd16.hip", "chain_pw16.hip", "scatter_patch.hip"]
 HEADERS = ["cnerf_dev.hpp", "cnerf_kernels.hpp", "field_common.hpp", "bwd16.hpp", "h3_dev.hpp", os.path.join("..", "..", "include", "cnerf.h")]
 # -ffp-contract=off: a*b+c is two roundings unless fmaf() is written (see csrc/cnerf_dev.hpp)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]

@@ -568,6 +568,7 @@ __global__ __launch_bounds__(256) void chain16_kernel(Chain16Args A) {
         float* sg = s_g + wave * 32 * 33;
         int* sb = s_base + wave * 32 * 8;
         float* sw = s_w + wave * 32 * 8;
+        int fi = 0;                                                          // index among the feature tiles (gin slab)
         for (int u = 0; u < n_l0_units; ++u) {
             const f16x8* unit = unit_begin(false);
             for (int sub = 0; sub < 2; ++sub) {
@@ -581,6 +582,19 @@ __global__ __launch_bounds__(256) void chain16_kernel(Chain16Args A) {
 #pragma unroll
                 for (int c = 0; c < KCH; ++c)
                     z = __builtin_amdgcn_mfma_f32_32x32x16_f16(unit[(sub * KCH + c) * 64 + lane], __builtin_bit_cast(f16x8, frag_in[c]), z, 0, 0, 0);
+                if (a.gin) {
+                    // ray passes: the tile's 32 x 32 gradients go to HBM in true units (128 B per point) and scatter_patch_kernel adds them
+                    // into the volume patch by patch, pre-reduced in LDS (scatter_patch.hip) -- a tile of 32 samples of one ray shares
+                    // almost no corners, 8 x 8 neighbouring pixels share most
+                    if (valid) {
+                        float* dst = a.gin + ((size_t)fi * (size_t)(a.total_tiles / a.tiles_per_image) * a.n_per_image + gpt) * 32 + 4 * h;
+#pragma unroll
+                        for (int gq = 0; gq < 4; ++gq)
+                            *reinterpret_cast<f32x4*>(dst + 8 * gq) = f32x4{z[4 * gq] * U0, z[4 * gq + 1] * U0, z[4 * gq + 2] * U0, z[4 * gq + 3] * U0};
+                    }
+                    ++fi;
+                    continue;
+                }
                 const int V = a.lvl_V[lvl], C = a.lvl_C[lvl];
                 Corner8 cr;
                 trilinear_corners(px, py, pz, a.half_voxel, V, cr);

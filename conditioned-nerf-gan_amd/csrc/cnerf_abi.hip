@@ -3,6 +3,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "cnerf_kernels.hpp"
@@ -880,7 +881,7 @@ int field_backward16_impl(const cnerf_cfg* cfg, uint32_t mode, int32_t group_ste
                           const float* phase, const float* cam2world, const float* u_strat, const float* fine_z,
                           const float* grad_rgb_sigma, const float* saved_rgb_sigma, void* act_feat16, void* act_h16, void* act_c16,
                           void* act_g16, void* act_go16, const float* scales, uint32_t* gmax, const cnerf_grad_volumes* grad_vols,
-                          uint32_t* sat, void* stream_) {
+                          uint32_t* sat, float* gin, void* stream_) {
     g_err[0] = 0;
     if (int rc = check_cfg(cfg, true)) return rc;
     Chain16Layout l;
@@ -940,9 +941,20 @@ int field_backward16_impl(const cnerf_cfg* cfg, uint32_t mode, int32_t group_ste
             return hip_fail(e, "chain16 (dry run)");
     }
     if (mode & CNERF_B16_CHAIN) {
+        // Ray passes: the chain stores its input-tile gradients (fp32, 128 B per point) and scatter_sorted_kernel adds them to the volume
+        // pre-reduced per pixel patch (scatter_patch.hip).  Default: the coarse pass only -- in the fine pass, whose depths are unordered
+        // along a ray, the chain's own atomics measured faster.  CNERF_SCATTER=chain / sorted force one path for both
+        // passes (A/B runs, tests/test_gpu_parity.py::test_sorted_patch_scatter_matches_the_chain_scatter); explicit points always
+        // take the chain's.
+        const char* sc_env = getenv("CNERF_SCATTER");
+        const bool force_chain = sc_env && !strcmp(sc_env, "chain"), force_sorted = sc_env && !strcmp(sc_env, "sorted");
+        const bool patch = gin && pass != 2 && !force_chain && (pass == 0 || force_sorted);
+        fa.gin = patch ? gin : nullptr;
         if (hipError_t e = launch_chain16(fa, cfg->H, base16, base16 + l.head_off, winv, scales, act_c16, act_g16, act_go16, nullptr, sat, l.n_mats, 0, 1,
                                           stream))
             return hip_fail(e, "chain16");
+        if (patch)
+            if (hipError_t e = launch_scatter_patch(fa, gin, stream)) return hip_fail(e, "scatter_patch");
     }
     return CNERF_OK;
 }
@@ -956,7 +968,7 @@ int cnerf_field_backward16(const cnerf_cfg* cfg, uint32_t mode, int32_t group_st
                            void* stream_) {
     return field_backward16_impl(cfg, mode, group_step, pass, image0, n_images, vols, packed, packed16, freq, phase, cam2world, u_strat, fine_z,
                                  grad_rgb_sigma, saved_rgb_sigma, act_feat16, act_h16, act_c16, act_g16, act_go16, scales, gmax, grad_vols, nullptr,
-                                 stream_);
+                                 nullptr, stream_);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -970,6 +982,7 @@ struct BackwardLayout {
     size_t a_feat, a_h, a_c, a_g, a_go;              // chunk buffers (a_feat / a_h / a_c absent when the forward kept its activations)
     size_t a_amax;                                   // per-point FiLM family: (L, T * 32) floats
     size_t a_gy;                                     // per-point FiLM family: L TB16 slabs of g_y
+    size_t a_gin;                                    // fp16 chain: (feature input tiles, chunk points, 32) fp32 input-tile gradients for scatter_patch_kernel
     size_t gmax, scales;                             // fp16: sampled maxima (n_mats + 1 uint32), {S, 1/S} pairs (n_mats + 1)
     size_t dwarg, cs, dwh, csh;                      // per-image reductions of one matrix: (cnt, H, 32 * max tiles), (cnt, H), (cnt, 4, H), (cnt, 4)
     size_t total;
@@ -1000,6 +1013,7 @@ int backward_layout(const cnerf_cfg* c, int bprec, int cnt, bool have_act16, Bac
         L.a_amax = take(have_act16 ? 0 : Lc * T * 32 * sizeof(float));
         L.a_g = take((3 * Lc * NT + 8) * T * 2048);
         L.a_go = take(T * 2048);
+        L.a_gin = 0;
         L.a_gy = take(Lc * NT * T * 2048);                          // two-kernel chain: g_y slabs
         L.gmax = take((5 * Lc + 2) * sizeof(uint32_t));             // 3 L + 2 sampled maxima, L of g_y, L of the stored derivatives
         L.scales = take((2 * (4 * Lc + 2) + 2 * Lc) * sizeof(float));   // {S, 1 / S} x (4 L + 2), then per layer {r, To}
@@ -1030,7 +1044,9 @@ int backward_layout(const cnerf_cfg* c, int bprec, int cnt, bool have_act16, Bac
         L.a_c = take(have_act16 ? 0 : (size_t)L.n_mats * T * NT * 2048);
         L.a_g = take((size_t)L.n_mats * T * NT * 2048);
         L.a_go = take(T * 2048);
+        L.a_gin = take((size_t)L.n_in * n * 32 * sizeof(float));
     } else {
+        L.a_gin = 0;
         L.a_feat = take(n * 32 * L.n_in * sizeof(float));
         L.a_h = take((size_t)L.n_mats * n * H * sizeof(float));
         L.a_c = take((size_t)L.n_mats * n * H * sizeof(float));
@@ -1272,11 +1288,11 @@ int cnerf_render_backward(const cnerf_cfg* cfg, int32_t bprec, int32_t cnt_max, 
                 step = step < 1 ? 1 : (step > 16 ? 16 : step);
                 if (int rc = field_backward16_impl(cfg, (have_act16 ? 0u : CNERF_B16_STORE) | CNERF_B16_DRY, (int)step, pass, b0, cnt, vols, packed, packed_bwd,
                                                    freq, phase, cam2world, rng->u_strat, saved->fine_z, g_out, s_out, a_feat, a_h, a_c, a_g, a_go, scales, gmax,
-                                                   grad_vols, nullptr, stream_))
+                                                   grad_vols, nullptr, nullptr, stream_))
                     return rc;
                 if (hipError_t e = launch_pow2_scales(gmax, L.n_mats, scales, stream)) return hip_fail(e, "pow2_scales");
                 if (int rc = field_backward16_impl(cfg, CNERF_B16_CHAIN, 1, pass, b0, cnt, vols, packed, packed_bwd, freq, phase, cam2world, rng->u_strat,
-                                                   saved->fine_z, g_out, s_out, a_feat, a_h, a_c, a_g, a_go, scales, gmax, grad_vols, saturated, stream_))
+                                                   saved->fine_z, g_out, s_out, a_feat, a_h, a_c, a_g, a_go, scales, gmax, grad_vols, saturated, (float*)(ws + L.a_gin), stream_))
                     return rc;
                 const size_t slab = (size_t)T * NT * 2048;             // bytes per matrix in a_h / a_g
                 for (int m = 0; m < L.n_mats; ++m) {

@@ -46,6 +46,8 @@ struct FieldArgs {
     const float* saved_out;  // (n,4) rgb_sigma of the forward (sigmoid')
     float* act_g;            // (L,n,H) d loss / d arg
     float* act_go;           // (n,4)   d loss / d head pre-activation
+    float* gin;              // chain16_kernel, ray passes: (feature input tiles, points of the launch, 32) fp32 gradients of the looked-up features,
+                             // scattered by scatter_patch_kernel; null: the chain scatters its tiles itself (explicit points)
     long long n_per_image;
     long long tiles_per_image;
     long long total_tiles;
@@ -182,6 +184,8 @@ struct GatherArgs {
     float half_voxel;
 };
 hipError_t launch_gather(const GatherArgs& a, hipStream_t stream);
+// scatter_patch.hip: feature-volume gradient of a ray pass from the chain's stored input-tile gradients, pre-reduced per pixel patch x depth bin in LDS
+hipError_t launch_scatter_patch(const FieldArgs& f, const float* gin, hipStream_t stream);
 hipError_t launch_scatter(const GatherArgs& a, const float* grad_feat, float* grad_fvol, hipStream_t stream);
 
 hipError_t launch_weight_grad(int cnt, long long npi, int H, int K, const float* G, const float* X, float* dW, float* colsum,

@@ -1377,6 +1377,52 @@ def test_forward_replays_from_a_hip_graph(dev, precision):
     assert not torch.equal(replayed[0], eager[0])
 
 
+@pytest.mark.parametrize("shape", [dict(B=2, R=11, S=10, V=40), dict(B=3, R=37, S=23, V=12), dict(B=1, R=64, S=24, V=64)])
+@pytest.mark.parametrize("variant", ["SHORTSIREN_FG", "SHORTSIREN_FG_Pyrmd"])
+def test_sorted_patch_scatter_matches_the_chain_scatter(dev, monkeypatch, shape, variant):
+    """The feature-volume gradient of the half-precision backward is added to the volume by scatter_sorted_kernel (scatter_patch.hip:
+    8 x 8-pixel patches x depth bins, corner records sorted by voxel in LDS, one add per run) from the input-tile gradients the chain
+    stores.  CNERF_SCATTER=chain makes the chain add its tiles itself (the path explicit points and, by default, the fine pass take):
+    the same addends in another order, so the volumes agree to fp32 summation noise.  Shapes: pixels ~3 voxels apart in a 40-voxel volume (most patches outgrow the
+    8-voxel window: the direct path), ragged patches / a ragged last quad / several images in a 12-voxel volume (everything inside one
+    window, long runs), and a 64-voxel volume at 64 x 64 rays; oblique cameras; a single level and the three-level pyramid."""
+    import cnerf_amd
+    from cnerf_amd.generators import ImplicitGenerator3d
+    from cnerf_amd.generators.volumetric_rendering import sample_camera_positions, create_cam2world_matrix
+    B, R, S, V = (shape[k] for k in "BRSV")
+    torch.manual_seed(R)
+    np.random.seed(R)
+    lv = [(32, V), (64, max(V // 2, 2)), (32, max(V // 4, 2))] if variant.endswith("Pyrmd") else [(32, V)]      # the pyramid's (channels, edge) per level
+    gen = ImplicitGenerator3d(variant, 32, sum(c for c, _ in lv), 4, 64).to(dev)
+    gen.set_device(dev)
+    gen.siren.precision, gen.siren.backward_precision = "fp16x3", "fp16"
+    gen.train()
+    vols = [torch.randn(B, c, v, v, v, device=dev, requires_grad=True) for c, v in lv]
+    glob = torch.randn(B, 32, device=dev)
+    cam = create_cam2world_matrix(sample_camera_positions(dev, "y", 0.9, 1.1, n=B), "y", device=dev)
+
+    def grads():
+        for v in vols:
+            v.grad = None
+        torch.manual_seed(11)
+        z = (vols[0] if len(vols) == 1 else list(vols), glob)
+        px, dp = gen(z, cam, R, 49.134342641202636, 0.25, 1.95, S, True, clamp_mode="relu", nerf_noise=1.0, white_back=True)
+        (px.square().mean() + dp.mean()).backward()
+        return [v.grad.detach().double().cpu() for v in vols]
+
+    monkeypatch.setenv("CNERF_SCATTER", "chain")
+    ref = grads()
+    monkeypatch.setenv("CNERF_SCATTER", "sorted")       # both passes through the sorted scatter (the fine pass: depth bins, queued candidates)
+    both = grads()
+    monkeypatch.delenv("CNERF_SCATTER")                  # the default: coarse pass sorted, fine pass by the chain
+    default = grads()
+    for got in (both, default):
+        for g, r_ in zip(got, ref):
+            assert r_.abs().max() > 0
+            assert ((g - r_).norm() / r_.norm()).item() < 2e-6
+            assert ((g - r_).abs().max() / r_.abs().max()).item() < 1e-5
+
+
 def test_half_precision_backward_reports_clamped_outliers(dev):
     """The fp16 backward stores d loss / d (sine argument) scaled by a power of two per matrix that comes from a SAMPLED maximum (every
     k-th tile group once there are >= 4096 of them: here 8192 groups, every 4th) with a factor 32 of headroom; anything beyond is
