@@ -8,9 +8,9 @@
 //                                                                                  0.43 flushed voxel rows per point: the reduction itself works)
 // ds_add_f32 retires one wave instruction per 194 cycles per CU on gfx950, ds_add_u32 per 5-6 (scripts/ubench/lds_atomic.hip): an exact
 // fp32 box needs owners, and eight owners (half-waves) per block doing dependent LDS round trips at two blocks per CU (the 64 KiB box)
-// are slower than the atomics they replace.  What could still win: a counting sort of the (voxel, point) pairs by LDS integer atomics and
-// per-voxel sums in registers (no box, ~20 KiB of LDS per block, 6-8 blocks per CU) -- not built; or a fixed-point box (ds_add_u32),
-// which would change the sums' rounding -- rejected.
+// are slower than the atomics they replace.  What won instead: a counting sort of the (voxel, point) records by LDS integer atomics and
+// per-run sums in registers (no box) -- csrc/scatter_patch.hip, the shipped kernel.  A fixed-point box (ds_add_u32) would change the
+// sums' rounding: rejected.
 //
 // scatter_patch_kernel: the feature-volume gradient of a rendering pass (the backward of the trilinear lookup, siren.py:555-567 ->
 // grid_sampler_3d_backward) from the stored input-tile gradients of the fp16 gradient chain, pre-reduced in LDS.
