@@ -11,7 +11,7 @@
 // sort on LDS integer atomics (ds_add_rtn_u32: 5-6 cycles per wave instruction; ds_add_f32 takes 194 -- scripts/ubench/lds_atomic.hip --
 // which is what stopped a box of fp32 sums in LDS, csrc/experiments/scatter_patch.hip); the points' gradient rows are parked in LDS;
 // then each half-wave walks an equal share of the sorted records, 32 channels across its lanes, sums a run of equal voxels in a register
-// and adds the run to the volume once (a 128-byte row per half-wave: the shape float atomics run at full rate in).  54 KiB of LDS per
+// and adds the run to the volume once (a 128-byte row per half-wave: the shape float atomics run at full rate in).  53.6 KiB of LDS per
 // block, three blocks per CU; sums stay fp32.  The window of a block is 8 x 8 x 8 voxels from the smallest voxel index of the 8 corners of
 // its frustum piece; a point with a corner outside it (0.3 % at 128 x 128 x 64 in a 64-voxel volume; most points when pixels are
 // several voxels apart) is added directly -- the result never depends on the window, only the number of atomics does.
@@ -19,7 +19,7 @@
 // Depth bins.  Coarse pass: bin q = strata 4q .. 4q+3 of every ray (the jitter keeps a sample inside its stratum): one round, one batch.
 // Fine pass: the resampled depths of a ray are unordered (inverse-CDF draws), so a block tests all S depths of its 64 rays against its bin
 // (16 depth loads in flight per lane, one result bit per round), queues the matches and processes a batch whenever 256 wait.  Measured at
-// batch 8, 128 x 128 x (64 + 64): coarse pass 17.4 -> 12.1 + ~0.8 ms; fine pass no gain (the 16 rounds cost what the reduction saves), so
+// batch 8, 128 x 128 x (64 + 64): coarse pass 17.4 -> 12.1 + 1.4 ms; fine pass no gain (the 16 rounds cost what the reduction saves), so
 // cnerf_render_backward sends only the coarse pass here by default (CNERF_SCATTER=sorted / chain force one path for both: A/B and tests).
 #include <hip/hip_runtime.h>
 
@@ -54,8 +54,10 @@ __global__ __launch_bounds__(256) void scatter_sorted_kernel(ScatterSortedArgs A
     uint2* rec = reinterpret_cast<uint2*>(rows + SS_PTS * 32);                   // [2048] {voxel << 8 | entry, weight bits}, sorted by voxel
     int* cnt = reinterpret_cast<int*>(rec + SS_PTS * 8);                         // [512] records per voxel, then (in place) their first index
     int* queue = cnt + SS_VOX;                                                   // [512] ring of point indices waiting for a batch
-    int* misc = queue + 2 * SS_PTS;                                              // [0] total records, [1] entries outside the window, [2] queue tail, [3..] those entries
-    int* s_corner = misc + 3 + SS_PTS;                                           // [8][3]
+    int* misc = queue + 2 * SS_PTS;                                              // [0] total records, [1] entries outside the window, [2] queue tail, [3] spare
+    int* s_corner = misc + 4;                                                    // [8][3]
+    unsigned char* outside = reinterpret_cast<unsigned char*>(s_corner + 24);    // [256] the entries outside the window
+    // (53.6 KiB in all: three blocks per CU with room for the allocation granule; a fourth KiB would cost the third block)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int R = a.geom.R, S = a.geom.S;
@@ -165,7 +167,7 @@ __global__ __launch_bounds__(256) void scatter_sorted_kernel(ScatterSortedArgs A
                         }
                     }
                 } else {
-                    misc[3 + atomicAdd(&misc[1], 1)] = tid;
+                    outside[atomicAdd(&misc[1], 1)] = (unsigned char)tid;
                 }
             }
 #pragma unroll
@@ -238,7 +240,7 @@ __global__ __launch_bounds__(256) void scatter_sorted_kernel(ScatterSortedArgs A
             {
                 const int n_out = misc[1];
                 for (int i = 2 * wave + h; i < n_out; i += 8) {
-                    const int e = misc[3 + i];
+                    const int e = outside[i];
                     float px, py, pz;
                     tile_point(a, b, (long long)queue[(base + e) & (2 * SS_PTS - 1)], true, 0, false, px, py, pz);
                     Corner8 cr;
@@ -309,7 +311,7 @@ hipError_t launch_scatter_patch(const FieldArgs& f, const float* gin, hipStream_
     const long long rows = f.n_per_image / ((long long)R * S);
     const long long blocks = (long long)A.n_images * ((rows + 7) / 8) * ((R + 7) / 8) * ((S + 3) / 4);
     if (blocks < 1 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
-    const size_t lds_bytes = (size_t)SS_PTS * 32 * 4 + (size_t)SS_PTS * 8 * 8 + (size_t)SS_VOX * 4 + (size_t)2 * SS_PTS * 4 + (size_t)(3 + SS_PTS) * 4 + 8 * 3 * 4;
+    const size_t lds_bytes = (size_t)SS_PTS * 32 * 4 + (size_t)SS_PTS * 8 * 8 + (size_t)SS_VOX * 4 + (size_t)2 * SS_PTS * 4 + 4 * 4 + 8 * 3 * 4 + SS_PTS;
     if (hipError_t e = hipFuncSetAttribute((const void*)scatter_sorted_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)) return e;
     hipLaunchKernelGGL(scatter_sorted_kernel, dim3((unsigned)blocks), dim3(256), lds_bytes, stream, A);
     return hipGetLastError();
