@@ -942,13 +942,12 @@ int field_backward16_impl(const cnerf_cfg* cfg, uint32_t mode, int32_t group_ste
     }
     if (mode & CNERF_B16_CHAIN) {
         // Ray passes: the chain stores its input-tile gradients (fp32, 128 B per point) and scatter_sorted_kernel adds them to the volume
-        // pre-reduced per pixel patch (scatter_patch.hip).  Default: the coarse pass only -- in the fine pass, whose depths are unordered
-        // along a ray, the chain's own atomics measured faster.  CNERF_SCATTER=chain / sorted force one path for both
-        // passes (A/B runs, tests/test_gpu_parity.py::test_sorted_patch_scatter_matches_the_chain_scatter); explicit points always
-        // take the chain's.
+        // pre-reduced per pixel patch (scatter_patch.hip); explicit points are added by the chain itself.  CNERF_SCATTER=chain makes the
+        // chain add the ray passes' too, CNERF_SCATTER=coarse sends only the coarse pass through the patch kernel (A/B runs and
+        // tests/test_gpu_parity.py::test_sorted_patch_scatter_matches_the_chain_scatter; DESIGN.md 3.7 has the three timings).
         const char* sc_env = getenv("CNERF_SCATTER");
-        const bool force_chain = sc_env && !strcmp(sc_env, "chain"), force_sorted = sc_env && !strcmp(sc_env, "sorted");
-        const bool patch = gin && pass != 2 && !force_chain && (pass == 0 || force_sorted);
+        const bool force_chain = sc_env && !strcmp(sc_env, "chain"), coarse_only = sc_env && !strcmp(sc_env, "coarse");
+        const bool patch = gin && pass != 2 && !force_chain && (pass == 0 || !coarse_only);
         fa.gin = patch ? gin : nullptr;
         if (hipError_t e = launch_chain16(fa, cfg->H, base16, base16 + l.head_off, winv, scales, act_c16, act_g16, act_go16, nullptr, sat, l.n_mats, 0, 1,
                                           stream))

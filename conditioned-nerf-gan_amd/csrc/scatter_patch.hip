@@ -18,9 +18,9 @@
 //
 // Depth bins.  Coarse pass: bin q = strata 4q .. 4q+3 of every ray (the jitter keeps a sample inside its stratum): one round, one batch.
 // Fine pass: the resampled depths of a ray are unordered (inverse-CDF draws), so a block tests all S depths of its 64 rays against its bin
-// (16 depth loads in flight per lane, one result bit per round), queues the matches and processes a batch whenever 256 wait.  Measured at
-// batch 8, 128 x 128 x (64 + 64): coarse pass 17.4 -> 12.1 + 1.4 ms; fine pass no gain (the 16 rounds cost what the reduction saves), so
-// cnerf_render_backward sends only the coarse pass here by default (CNERF_SCATTER=sorted / chain force one path for both: A/B and tests).
+// (16 depth loads in flight per lane, one result bit per round), queues the matches and processes a batch whenever 256 wait; a tail of at
+// most 48 points is added directly.  bench.py train_step at batch 8, 128 x 128 x (64 + 64), random cameras: 84.2 ms with the chain's own
+// atomics, 77.6 with the coarse pass here, 74.9 with both (the default; CNERF_SCATTER=chain / coarse select the others: A/B and tests).
 #include <hip/hip_runtime.h>
 
 #include "cnerf_kernels.hpp"
@@ -31,7 +31,8 @@ namespace cnerf {
 namespace {
 constexpr int SS_BOX = 8;                                   // voxel window per axis
 constexpr int SS_VOX = SS_BOX * SS_BOX * SS_BOX;
-constexpr int SS_PTS = 256;                                 // points per block: 64 rays x 4 strata
+constexpr int SS_PTS = 256;                                 // points per batch (coarse pass: 64 rays x 4 strata)
+constexpr int SS_DIRECT = 48;                               // a last batch of at most this many points skips the sort
 
 struct ScatterSortedArgs {
     FieldArgs f;          // geometry, mode (COARSE / FINE), u_strat / fine_z / philox, levels, gradient volumes (of the launch's first image)
@@ -253,6 +254,21 @@ __global__ __launch_bounds__(256) void scatter_sorted_kernel(ScatterSortedArgs A
             __syncthreads();                                                     // before rows / rec / cnt / the queue slots are reused
         };
 
+        // ---- a handful of queued points (the tail of a fine-pass bin, a sliver of a patch at the image edge): straight to the volume, two
+        // per wave instruction -- a batch costs its barriers and latencies whatever it holds
+        auto direct = [&](int base, int n) {
+            for (int i = 2 * wave + h; i < n; i += 8) {
+                const long long nnd = queue[(base + i) & (2 * SS_PTS - 1)];
+                float px, py, pz;
+                tile_point(a, b, nnd, true, 0, false, px, py, pz);
+                Corner8 cr;
+                trilinear_corners(px, py, pz, a.half_voxel, V, cr);
+                const float gval = gin[(size_t)nnd * 32 + ch];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) atomicAdd(gv + (size_t)cr.base[k] * C + ch, gval * cr.w[k]);
+            }
+        };
+
         // ---- rounds: a quad of samples per ray; the points of this block's depth bin queue up and leave in batches of 256 -----------------
         // Fine pass: which of the next 16 quads' samples fall in the bin is decided up front from 16 depth loads in flight together
         // (one bit per round in a register), not one dependent load per round.
@@ -289,7 +305,8 @@ __global__ __launch_bounds__(256) void scatter_sorted_kernel(ScatterSortedArgs A
                 const bool last = q0 + j + 1 == q_end;
                 while (avail >= SS_PTS || (last && avail > 0)) {
                     const int n = avail < SS_PTS ? avail : SS_PTS;
-                    process_batch(done, n);
+                    if (n <= SS_DIRECT) direct(done, n);
+                    else process_batch(done, n);
                     done += n;
                     avail -= n;
                 }

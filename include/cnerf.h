@@ -400,10 +400,10 @@ typedef struct cnerf_saved {
     const float* fine_z;           /* (B,P,S) or NULL: the depths the fine pass used */
 } cnerf_saved;
 
-/* Half-precision backward, feature-volume gradient: the coarse pass's input-tile gradients go through the workspace (128 B per point)
- * and are added to grad_vols pre-reduced per 8 x 8-pixel patch (csrc/scatter_patch.hip); the fine pass and explicit points are added by
- * the gradient chain itself.  Same addends either way.  Environment CNERF_SCATTER=chain | sorted forces one path for both ray passes
- * (A/B runs and tests only). */
+/* Half-precision backward, feature-volume gradient: the ray passes' input-tile gradients go through the workspace (128 B per point) and
+ * are added to grad_vols pre-reduced per 8 x 8-pixel patch (csrc/scatter_patch.hip); explicit points are added by the gradient chain
+ * itself.  Same addends either way.  Environment CNERF_SCATTER=chain | coarse makes the chain add both ray passes' / the fine pass's
+ * too (A/B runs and tests only). */
 int cnerf_backward_workspace_bytes(const cnerf_cfg* cfg, int32_t backward_precision, int32_t images_per_chunk, int32_t have_act16,
                                    size_t* bytes);
 int cnerf_render_backward(const cnerf_cfg* cfg, int32_t backward_precision, int32_t images_per_chunk, const cnerf_volumes* vols,

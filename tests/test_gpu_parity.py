@@ -1382,8 +1382,8 @@ def test_forward_replays_from_a_hip_graph(dev, precision):
 def test_sorted_patch_scatter_matches_the_chain_scatter(dev, monkeypatch, shape, variant):
     """The feature-volume gradient of the half-precision backward is added to the volume by scatter_sorted_kernel (scatter_patch.hip:
     8 x 8-pixel patches x depth bins, corner records sorted by voxel in LDS, one add per run) from the input-tile gradients the chain
-    stores.  CNERF_SCATTER=chain makes the chain add its tiles itself (the path explicit points and, by default, the fine pass take):
-    the same addends in another order, so the volumes agree to fp32 summation noise.  Shapes: pixels ~3 voxels apart in a 40-voxel volume (most patches outgrow the
+    stores.  CNERF_SCATTER=chain makes the chain add its tiles itself (the path explicit points take): the same addends in another
+    order, so the volumes agree to fp32 summation noise.  Shapes: pixels ~3 voxels apart in a 40-voxel volume (most patches outgrow the
     8-voxel window: the direct path), ragged patches / a ragged last quad / several images in a 12-voxel volume (everything inside one
     window, long runs), and a 64-voxel volume at 64 x 64 rays; oblique cameras; a single level and the three-level pyramid."""
     import cnerf_amd
@@ -1412,15 +1412,17 @@ def test_sorted_patch_scatter_matches_the_chain_scatter(dev, monkeypatch, shape,
 
     monkeypatch.setenv("CNERF_SCATTER", "chain")
     ref = grads()
-    monkeypatch.setenv("CNERF_SCATTER", "sorted")       # both passes through the sorted scatter (the fine pass: depth bins, queued candidates)
-    both = grads()
-    monkeypatch.delenv("CNERF_SCATTER")                  # the default: coarse pass sorted, fine pass by the chain
+    monkeypatch.setenv("CNERF_SCATTER", "coarse")       # the coarse pass through the sorted scatter, the fine pass by the chain
+    coarse = grads()
+    monkeypatch.delenv("CNERF_SCATTER")                  # the default: both ray passes sorted (the fine pass: depth bins, queued candidates)
     default = grads()
-    for got in (both, default):
+    for got in (coarse, default):
         for g, r_ in zip(got, ref):
             assert r_.abs().max() > 0
-            assert ((g - r_).norm() / r_.norm()).item() < 2e-6
-            assert ((g - r_).abs().max() / r_.abs().max()).item() < 1e-5
+            # fp32 sums of the same addends in two orders: 2e-7 .. 4e-7 apart in the 40- and 64-voxel volumes, ~2e-6 in the pyramid's 3-voxel level
+            # (each of its 27 voxels sums ~2e4 addends); a single point lost or added twice would show at 1e-3 or more
+            assert ((g - r_).norm() / r_.norm()).item() < 2e-5
+            assert ((g - r_).abs().max() / r_.abs().max()).item() < 1e-4
 
 
 def test_half_precision_backward_reports_clamped_outliers(dev):
